@@ -1,0 +1,243 @@
+"""Independent pins of the CPU oracle (the reference holds no golden vectors for this path:
+SURVEY.md section 8c).  Each test checks the restatement against something that is NOT the
+restatement: numpy.fft, a float64 centred-k Fourier sum, closed-form plane waves, numpy's
+MT19937, float64 formulas."""
+
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("N", [64, 256])
+def test_stockham_rows_is_N_times_ifft(oracle, N):
+    rng = np.random.default_rng(N)
+    f = rng.standard_normal((N, N, 2)).astype(np.float32)
+    got = oracle.fftx(f)
+    z = f[..., 0].astype(np.float64) + 1j * f[..., 1]
+    want = np.fft.ifft(z, axis=1) * N
+    err = np.abs((got[..., 0] + 1j * got[..., 1]) - want).max() / np.abs(want).max()
+    # fp32 Stockham with the reference table: its angles are unreduced fp32 (up to pi*N), so the
+    # twiddle error, and with it the transform error, grows like N * 1e-7
+    assert err < 1.5e-7 * N
+
+
+@pytest.mark.parametrize("N", [64, 256])
+def test_stockham_columns_is_N_times_ifft(oracle, N):
+    rng = np.random.default_rng(N + 1)
+    f = rng.standard_normal((N, N, 2)).astype(np.float32)
+    got = oracle.ffty(f)
+    z = f[..., 0].astype(np.float64) + 1j * f[..., 1]
+    want = np.fft.ifft(z, axis=0) * N
+    err = np.abs((got[..., 0] + 1j * got[..., 1]) - want).max() / np.abs(want).max()
+    # fp32 Stockham with the reference table: its angles are unreduced fp32 (up to pi*N), so the
+    # twiddle error, and with it the transform error, grows like N * 1e-7
+    assert err < 1.5e-7 * N
+
+
+def test_weights_table(oracle):
+    # src/renderer/ocean.cpp:694-695: lane i, stage s -> exp(-2*pi*i*I / 2^(s+1)), i the FULL lane index
+    N = 64
+    w = oracle.weights(N)
+    i = np.arange(N)[:, None]
+    s = np.arange(6)[None, :]
+    ang = -2 * np.pi * i / (2.0 ** (s + 1))
+    # unreduced fp32 angle -> absolute error up to ~ |angle| * 6e-8 (worst at stage 0, lane N-1)
+    assert np.abs(w[:, 0::2] - np.cos(ang)).max() < 1e-7 * np.pi * N
+    assert np.abs(w[:, 1::2] - np.sin(ang)).max() < 1e-7 * np.pi * N
+    # and it is exactly the fp32 expression of ocean.cpp:694
+    a32 = (np.float32(-2) * np.float32(np.pi) * i.astype(np.float32)) / (np.float32(2) * np.float32(2.0) ** s.astype(np.float32))
+    assert a32.dtype == np.float32
+    assert np.abs(w[:, 0::2] - np.cos(a32.astype(np.float64))).max() < 1e-7
+
+
+def test_end_to_end_is_centred_k_sum(oracle):
+    # displacement dz(x,y) == Re sum_k h~(k) exp(i k.x) with k centred (index - N/2): the (-1)^(x+y) of
+    # ocean.map.comp:60 is exactly the half-grid shift of the spectrum.
+    N = 64
+    p = oracle.EXAMPLE
+    _, h0 = oracle.seed(N, 1000)
+    phase = np.zeros((N, N), np.float32)
+    for _ in range(7):
+        oracle.update(phase, p["wavescale"], 1 / 60)
+    scale = np.float32(1) / np.float32(p["wavescale"])
+    h, hx, hy = oracle.sim(h0, phase, scale)
+    m = oracle.displace(h0, phase.copy(), p["wavescale"], p["choppiness"], dt=0.0)
+
+    n = np.arange(N) - N // 2
+    E = np.exp(2j * np.pi * np.outer(np.arange(N), n) / N)  # [x, n]
+    for field, comp, mul in ((h, 2, 1.0), (hx, 0, p["choppiness"]), (hy, 1, p["choppiness"])):
+        z = field[..., 0].astype(np.float64) + 1j * field[..., 1]  # [m, n]
+        full = E @ z.T  # [x, m] -> sum over n
+        full = (E @ full.T)  # [y, x] sum over m
+        want = full.real * mul
+        got = m[0, :, :, comp]
+        assert np.abs(got - want).max() < 1e-5 * max(1.0, np.abs(want).max()), comp
+        assert np.sqrt(((got - want) ** 2).mean()) < 3e-6, comp
+    # the transform output is NOT real: the -k partner index is (N-1-y, N-1-x)
+    assert np.abs(full.imag).std() > 0.1 * np.abs(full.real).std()
+
+
+def test_single_bin_plane_wave(oracle):
+    # one nonzero h0 bin -> h~ has two bins (k and its sim.comp:59 partner); check the k bin travels at
+    # omega(k) and the displacement is the closed-form sum of the two plane waves.
+    N = 64
+    wavescale = 22.0
+    scale = np.float32(1) / np.float32(wavescale)
+    m0, n0 = 40, 45
+    h0 = np.zeros((N, N, 2), np.float32)
+    h0[m0, n0] = (0.3, -0.2)
+    phase = np.zeros((N, N), np.float32)
+    steps = 25
+    for _ in range(steps):
+        oracle.update(phase, wavescale, 1 / 60)
+    kx = 2 * np.pi * (n0 - N / 2) / wavescale
+    ky = 2 * np.pi * (m0 - N / 2) / wavescale
+    k = np.hypot(kx, ky)
+    omega = np.sqrt(9.81 * k * (1 + k * k / 370.0**2))
+    t = steps / 60
+    assert abs(phase[m0, n0] - (omega * t) % (2 * np.pi)) < 5e-5
+    assert abs(oracle.dispersion(kx, ky) - omega) < 1e-5 * omega
+
+    out = oracle.displace(h0, phase.copy(), wavescale, 1.35, dt=0.0)
+    a = 0.3 - 0.2j
+    y, x = np.mgrid[0:N, 0:N]
+    ph1 = float(phase[m0, n0])
+    m1, n1 = N - 1 - m0, N - 1 - n0
+    ph2 = float(phase[m1, n1])
+    w1 = a * np.exp(1j * ph1) * np.exp(2j * np.pi * ((n0 - N / 2) * x + (m0 - N / 2) * y) / N)
+    w2 = np.conj(a) * np.exp(-1j * ph2) * np.exp(2j * np.pi * ((n1 - N / 2) * x + (m1 - N / 2) * y) / N)
+    want = (w1 + w2).real
+    assert np.abs(out[0, :, :, 2] - want).max() < 2e-5
+
+
+def test_seeding_order_matches_mt19937(oracle):
+    # src/renderer/ocean.cpp:109-146: polar pairs drawn row-major (m outer, n inner) from std::mt19937 through
+    # uniform_real_distribution<float>(-1,1).  Independent restatement with numpy's MT19937 (init_genrand seeding).
+    N = 16
+    seed = 1234
+    s, _ = oracle.seed(N, seed)
+    bg = np.random.MT19937()
+    bg._legacy_seeding(seed)
+    raw = iter(bg.random_raw(8 * 2 * N * N).astype(np.uint32))
+
+    def real11():
+        r = np.float32(next(raw)) / np.float32(4294967296.0)
+        if r >= 1:
+            r = np.nextafter(np.float32(1), np.float32(0))
+        return np.float32(r * np.float32(2.0) + np.float32(-1.0))
+
+    want = np.empty((N, N, 2), np.float32)
+    for m in range(N):
+        for n in range(N):
+            x = y = np.float32(0)
+            w = np.float32(1)
+            i = 0
+            while i < 8 and not (0 < w < 1):
+                x, y = real11(), real11()
+                w = np.float32(x * x + y * y)
+                i += 1
+            g = np.sqrt(np.float32(-2) * np.log(w) / w, dtype=np.float32)
+            want[m, n] = (x * g, y * g)
+    assert np.abs(s - want).max() < 1e-6
+    assert (s == want).mean() > 0.85  # logf/sqrtf differ by an ulp between libm and numpy on a few points
+
+
+def test_phillips_and_h0(oracle):
+    p = oracle.EXAMPLE
+    w = p["winddirection"]
+    assert oracle.phillips(0, 0, 1, 1, 1, 0) == 0.0
+    for kx, ky in ((0.3, 0.1), (-2.0, 1.5), (10.0, -7.0)):
+        k2 = kx * kx + ky * ky
+        L = p["windspeed"] ** 2 / 9.81
+        kw = kx * w[0] + ky * w[1]
+        want = p["waveamplitude"] * (0.2 if kw < 0 else 1.0) * np.exp(-1 / (k2 * L * L)) / k2**3 * kw * kw * np.exp(-k2 * L * L * 1e-6)
+        got = oracle.phillips(kx, ky, p["waveamplitude"], p["windspeed"], w[0], w[1])
+        assert abs(got - want) <= 2e-6 * abs(want)
+    N = 64
+    s, h0 = oracle.seed(N, 7)
+    assert np.all(h0[N // 2, N // 2] == 0)  # k = 0 bin
+    dk = 2 * np.pi / p["wavescale"]
+    m, n = 20, 50
+    ph = oracle.phillips(dk * (n - N / 2), dk * (m - N / 2), p["waveamplitude"], p["windspeed"], w[0], w[1])
+    assert np.allclose(h0[m, n], s[m, n] * dk * np.sqrt(ph / 2), rtol=1e-5)
+
+
+def test_map_normals_and_signs(oracle):
+    N = 64
+    rng = np.random.default_rng(3)
+    h, hx, hy = (rng.standard_normal((N, N, 2)).astype(np.float32) for _ in range(3))
+    scale, chop = np.float32(1 / 22), np.float32(1.35)
+    m = oracle.make_map(h, hx, hy, scale, chop)
+    y, x = np.mgrid[0:N, 0:N]
+    sg = np.where((x + y) & 1, -1.0, 1.0)
+    dz = h[..., 0] * sg
+    assert np.array_equal(m[0, ..., 2], dz.astype(np.float32))
+    assert np.allclose(m[0, ..., 0], hx[..., 0] * sg * chop, rtol=1e-6)
+    nx = np.roll(dz, 1, axis=1) - np.roll(dz, -1, axis=1)
+    ny = np.roll(dz, -1, axis=0) - np.roll(dz, 1, axis=0)
+    nz = 4 / (float(scale) * N)
+    ln = np.sqrt(nx * nx + ny * ny + nz * nz)
+    assert np.allclose(m[1, ..., 0], nx / ln, atol=1e-6)
+    assert np.allclose(m[1, ..., 1], ny / ln, atol=1e-6)
+    assert np.allclose(m[1, ..., 2], nz / ln, atol=1e-6)
+    assert np.all(m[..., 3] == 0)
+
+
+def test_gen_and_indices(oracle):
+    N = 64
+    p = oracle.EXAMPLE
+    _, h0 = oracle.seed(N, 1000)
+    phase = np.zeros((N, N), np.float32)
+    m = oracle.displace(h0, phase, p["wavescale"], p["choppiness"], dt=1 / 60)
+    s = oracle.example_oceanset(N, swellphase=0.3)
+    # camera sits at (0,0,8) looking down +x: translation recovered from the dual quaternion
+    v = oracle.gen(s, m, 32, 32)
+    assert np.isfinite(v).all()
+    assert np.all(v[..., 11] == -1)
+    nrm = np.linalg.norm(v[..., 5:8], axis=-1)
+    assert np.allclose(nrm, 1, atol=1e-5)
+    assert np.allclose(v[..., 3:5] * 10, v[..., 0:2] + 0, atol=2.0)  # texcoord = 0.1*undisplaced position
+    # flat sea, no swell: rays that hit the plane land on z == 0 and normals are +z
+    flat = np.zeros_like(m)
+    flat[1, ..., 2] = 1
+    s2 = oracle.example_oceanset(N, params=dict(swellamplitude=0.0))
+    v2 = oracle.gen(s2, flat, 16, 16)
+    assert np.allclose(v2[..., 2], 0, atol=1e-6)
+    assert np.allclose(v2[..., 5:8], (0, 0, 1), atol=1e-5)
+    idx = oracle.indices(4, 3)
+    assert idx.size == 6 * 3 * 2
+    assert list(idx[:6]) == [4, 0, 5, 5, 0, 1]
+    assert idx.max() == 11
+
+
+def test_seed_rejection_limit(oracle):
+    # ocean.cpp:115: 8 tries, then sqrt(-2 log(w) / w) of a rejected w -> NaN.  Literal mode keeps it,
+    # sanitize zeroes exactly those pairs and nothing else.
+    N = 512
+    s_lit, h_lit, rej = oracle.seed(N, 1000, sanitize=False, return_rejected=True)
+    s_san, h_san, rej2 = oracle.seed(N, 1000, sanitize=True, return_rejected=True)
+    assert rej == rej2
+    bad = ~np.isfinite(s_lit).all(axis=-1)
+    assert bad.sum() == rej
+    assert np.array_equal(s_lit[~bad], s_san[~bad])
+    assert np.all(s_san[bad] == 0)
+    assert np.isfinite(h_san).all()
+    # N = 64 with the seeds the fixtures use has no rejected pair: literal == sanitised
+    for sd in (1000, 1001, 1002, 1003):
+        a, _, r = oracle.seed(64, sd, sanitize=False, return_rejected=True)
+        assert r == 0 and np.isfinite(a).all()
+
+
+@pytest.mark.parametrize("N", [64, 512])
+def test_reduced_table_is_the_accurate_one(oracle, N):
+    # literal table: error grows with N; reduced table: stays at fp32 rounding level
+    rng = np.random.default_rng(5)
+    f = rng.standard_normal((N, N, 2)).astype(np.float32)
+    z = f[..., 0].astype(np.float64) + 1j * f[..., 1]
+    want = np.fft.ifft(z, axis=1) * N
+    lit = oracle.fftx(f, oracle.weights(N))
+    red = oracle.fftx(f, oracle.weights(N, reduced=True))
+    e_lit = np.abs((lit[..., 0] + 1j * lit[..., 1]) - want).max() / np.abs(want).max()
+    e_red = np.abs((red[..., 0] + 1j * red[..., 1]) - want).max() / np.abs(want).max()
+    assert e_red < 1e-6
+    assert e_lit > e_red
+    assert np.abs(oracle.weights(N) - oracle.weights(N, reduced=True)).max() < 1e-7 * np.pi * N
