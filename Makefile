@@ -1,0 +1,36 @@
+# Builds the HIP module (C ABI of include/datum_ocean_hip.h) for gfx950, the C++ host shim and the CPU oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function
+
+LIB = datum_amd/lib/libdatum_ocean_hip.so
+SRC = datum_amd/csrc/ocean_capi.hip
+DEPS = datum_amd/csrc/ocean_kernels.hip datum_amd/csrc/ocean_fft_core.h include/datum_ocean_hip.h
+
+HOSTLIB = datum_amd/lib/libdatum_ocean_host.so
+HOSTSRC = datum_amd/host/ocean.cpp datum_amd/host/host_capi.cpp
+HOSTDEPS = datum_amd/host/ocean.h datum_amd/host/lml.h include/datum_ocean_hip.h
+CXX ?= g++
+HOSTFLAGS ?= -O2 -std=c++14 -fPIC -ffp-contract=off -fno-fast-math -Wall
+
+all: $(LIB) $(HOSTLIB) oracle
+
+# the C++ host shim links only against the C ABI of the HIP module
+$(HOSTLIB): $(HOSTSRC) $(HOSTDEPS) $(LIB)
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOSTSRC) -Ldatum_amd/lib -ldatum_ocean_hip -Wl,-rpath,'$$ORIGIN'
+
+$(LIB): $(SRC) $(DEPS)
+	@mkdir -p datum_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC)
+
+oracle:
+	$(MAKE) -C oracle liboracle.so
+
+resource-usage: $(SRC) $(DEPS)
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(SRC) 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" 
+
+clean:
+	rm -f $(LIB) $(HOSTLIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean resource-usage

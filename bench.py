@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- ocean grids/s (N x N displacement step) on MI355X, one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one update_ocean(dt = 1/60) + one displacement pass (phase advance, ocean.sim, row IFFT, column IFFT,
+ocean.map: SURVEY.md 8d) over this rank's batch of independent cascades.  Default workload = BASELINE.json
+configs[2]: 1024 x 1024 x 4 cascades per GPU (the size north_star's 70 % target is quoted on).  Cascades /
+tiles are independent, so N GPUs run N batches (weak scaling, no data-path collective); north_star's
+"single RCCL all-gather" that reassembles the displacement field is issued once per timed batch of K steps
+and is inside the timed region (--gather none leaves it out; the JSON reports its cost separately).
+
+Prints ONE JSON line on rank 0.  value = all grids of all ranks / max-over-ranks wall time.
+Inputs: example-ocean parameters, seeds mt19937(1000 + global cascade index), synthetic by construction.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+CASCADE_WAVESCALES = (22.0, 64.0, 176.0, 512.0)
+DT = np.float32(1.0 / 60.0)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--resolution", type=int, default=1024)
+    ap.add_argument("--cascades", type=int, default=4)
+    ap.add_argument("--gather", choices=("batch", "none"), default="batch")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
+    return ap.parse_args()
+
+
+def cpu_baseline(N, cascades, states, budget):
+    """The oracle (oracle/ocean_oracle.cpp, OpenMP over rows / columns) timed on this host on a bounded sample of
+    the same workload.  A reported baseline, not a target.  kind = "port": the reference itself cannot be built or
+    run here (no Vulkan / lavapipe / glslang / leap: DESIGN.md)."""
+    from oracle import oracle
+
+    w = oracle.weights(N)
+    scratch = np.empty(6 * N * N, np.float32)
+    out = np.empty((2, N, N, 4), np.float32)
+    phases = [np.zeros((N, N), np.float32) for _ in range(cascades)]
+    # untimed touch
+    oracle.displace(states[0][0], phases[0], states[0][1], 1.35, dt=DT, w=w, mt=True, scratch=scratch, out=out)
+    grids = 0
+    t0 = time.perf_counter()
+    while True:
+        for c in range(cascades):
+            oracle.displace(states[c][0], phases[c], states[c][1], 1.35, dt=DT, w=w, mt=True, scratch=scratch, out=out)
+            grids += 1
+        el = time.perf_counter() - t0
+        if el >= budget or grids >= 64 * cascades:
+            break
+    return dict(value=grids / el, unit="grids/s", cores=oracle.num_threads(), kind="port",
+                sample=f"{grids} grids = {grids // cascades} steps of {N}x{N} x {cascades} cascades in {el:.1f} s, "
+                       f"oracle/ocean_oracle.cpp with OpenMP over rows/columns")
+
+
+def main():
+    args = parse()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from datum_amd import capi, host_api
+
+    N, C = args.resolution, args.cascades
+    dev = torch.device("cuda", local_rank)
+
+    # state: this rank's cascades, seeded on the host exactly as seed_ocean does (mt19937(1000 + global index))
+    oc = capi.Ocean(N, C, device=local_rank)
+    states = []
+    for c in range(C):
+        g = rank * C + c
+        ws = CASCADE_WAVESCALES[c % len(CASCADE_WAVESCALES)]
+        p = host_api.OceanParams(N, **dict(host_api.EXAMPLE_TUNABLES, wavescale=ws))
+        p.seed_ocean(1000 + g)
+        oc.set_cascade(c, ws, 1.35)
+        oc.upload_state(c, p.height)
+        if rank == 0 and world == 1:
+            states.append((p.height.copy(), ws))
+        del p
+
+    # maps land in a torch tensor so that RCCL can gather them in place; kernels run on torch's stream
+    maps = torch.empty(C * 2 * N * N * 4, dtype=torch.float32, device=dev)
+    oc.bind_maps(maps.data_ptr(), maps.numel() * 4)
+    stream = torch.cuda.current_stream(dev)
+    oc.set_stream(stream.cuda_stream)
+    gathered = torch.empty(world * maps.numel(), dtype=torch.float32, device=dev) if (world > 1 and args.gather == "batch") else None
+
+    def step():
+        oc.update(DT)
+        oc.displace()
+
+    for _ in range(args.warmup):
+        step()
+    if gathered is not None:
+        dist.all_gather_into_tensor(gathered, maps)
+
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    oc.profile_begin(args.steps)
+    ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    if gathered is not None:
+        dist.all_gather_into_tensor(gathered, maps)
+    ev2.record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+
+    row_ms, col_ms, nprof = oc.profile_end()
+    compute_ms = ev0.elapsed_time(ev1)
+    gather_ms = ev1.elapsed_time(ev2) if gathered is not None else 0.0
+
+    if world > 1:
+        t = torch.tensor([elapsed, compute_ms, gather_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, compute_ms, gather_ms = (float(v) for v in t.tolist())
+
+    if rank == 0:
+        # sanity: the maps of the last step are finite and non-trivial
+        chk = maps[: 2 * N * N * 4].view(2, N, N, 4)
+        assert bool(torch.isfinite(chk).all()) and float(chk[0, ..., 2].abs().max()) > 0
+
+        grids = args.steps * C * world
+        row_b, col_b = oc.algorithmic_bytes()
+        dom = ("colpass", col_ms, col_b) if col_ms >= row_ms else ("rowpass", row_ms, row_b)
+        ach = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+        step_ach = (row_b + col_b) / ((row_ms + col_ms) * 1e-3) / 1e9 if row_ms + col_ms > 0 else 0.0
+
+        line = {
+            "metric": "ocean grids/sec (N x N displacement step)",
+            "value": grids / elapsed,
+            "unit": "grids/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{N}x{N} x {C} cascades per GPU, fp32, phase advance + sim + row IFFT + column IFFT + map "
+                            f"(BASELINE.json configs[2])" if (N, C) == (1024, 4) else f"{N}x{N} x {C} cascades per GPU, fp32",
+                "resolution": N,
+                "cascades_per_gpu": C,
+                "grids_per_step": C * world,
+                "gather": args.gather if world > 1 else "n/a (1 GPU)",
+                "parallelism": f"tile-farm x{world}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": f"ocean_{dom[0]}_kernel<{N}>",
+                "achieved": ach,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_launch": dom[2],
+                "ms_per_launch": dom[1],
+                "rowpass": {"ms": row_ms, "bytes": row_b, "GBps": row_b / (row_ms * 1e-3) / 1e9 if row_ms > 0 else 0.0},
+                "colpass": {"ms": col_ms, "bytes": col_b, "GBps": col_b / (col_ms * 1e-3) / 1e9 if col_ms > 0 else 0.0},
+                "step_GBps": step_ach,
+                "step_frac": step_ach / HBM_PEAK_GBS,
+                "launches_timed": nprof,
+            },
+            "compute_ms": compute_ms,
+            "gather_ms": gather_ms,
+            "value_compute_only": grids / (compute_ms * 1e-3) if compute_ms > 0 else None,
+        }
+
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(N, C, states, args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+
+        print(json.dumps(line), flush=True)
+
+    oc.bind_maps(0, 0)
+    oc.set_stream(0)
+    oc.close()
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,220 @@
+"""ctypes binding of include/datum_ocean_hip.h (libdatum_ocean_hip.so).
+
+No compute happens here and there is no fallback: if the library is missing, import-time loading raises.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(_HERE, "lib", "libdatum_ocean_hip.so")
+
+F = ctypes.c_float
+I = ctypes.c_int
+P = ctypes.c_void_p
+D = ctypes.c_double
+
+SUPPORTED = (64, 128, 256, 512, 1024, 2048, 4096)
+MAX_CASCADES = 16
+
+OK, EINVAL, ESTATE, ENOMEM = 0, -1, -2, -3
+
+
+class OceanSet(ctypes.Structure):
+    """datum_ocean_set == head of the reference's OceanSet (src/renderer/ocean.cpp:33-50), 216 bytes."""
+
+    _fields_ = [
+        ("proj", F * 16),
+        ("invproj", F * 16),
+        ("camera_real", F * 4),
+        ("camera_dual", F * 4),
+        ("plane", F * 4),
+        ("swelllength", F),
+        ("swellamplitude", F),
+        ("swellsteepness", F),
+        ("swellphase", F),
+        ("swelldirection", F * 2),
+        ("scale", F),
+        ("choppiness", F),
+        ("smoothing", F),
+        ("size", ctypes.c_uint32),
+    ]
+
+
+assert ctypes.sizeof(OceanSet) == 216
+
+# every symbol include/datum_ocean_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "datum_ocean_create": (I, [ctypes.POINTER(P), I, I, I]),
+    "datum_ocean_destroy": (I, [P]),
+    "datum_ocean_set_stream": (I, [P, P]),
+    "datum_ocean_bind_maps": (I, [P, P, ctypes.c_size_t]),
+    "datum_ocean_maps_device": (I, [P, ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]),
+    "datum_ocean_set_cascade": (I, [P, I, F, F]),
+    "datum_ocean_upload_state": (I, [P, I, P, P]),
+    "datum_ocean_read_state": (I, [P, I, P]),
+    "datum_ocean_update": (I, [P, F]),
+    "datum_ocean_displace": (I, [P]),
+    "datum_ocean_gen": (I, [P, I, ctypes.POINTER(OceanSet), I, I, P]),
+    "datum_ocean_read_maps": (I, [P, I, P]),
+    "datum_ocean_sync": (I, [P]),
+    "datum_ocean_wait_event": (I, [P, P]),
+    "datum_ocean_signal": (I, [P, ctypes.POINTER(P)]),
+    "datum_ocean_device_alloc": (I, [P, ctypes.c_size_t, ctypes.POINTER(P)]),
+    "datum_ocean_device_free": (I, [P, P]),
+    "datum_ocean_device_write": (I, [P, P, P, ctypes.c_size_t]),
+    "datum_ocean_device_read": (I, [P, P, P, ctypes.c_size_t]),
+    "datum_ocean_last_error": (ctypes.c_char_p, [P]),
+    "datum_ocean_reference_weights": (I, [I, P]),
+    "datum_ocean_debug_sim": (I, [P, I, P, P, P]),
+    "datum_ocean_debug_rowpass": (I, [P, I, P, P, P]),
+    "datum_ocean_profile_begin": (I, [P, I]),
+    "datum_ocean_profile_end": (I, [P, ctypes.POINTER(D), ctypes.POINTER(D), ctypes.POINTER(I)]),
+    "datum_ocean_algorithmic_bytes": (I, [P, ctypes.POINTER(D), ctypes.POINTER(D)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP module.  Raises OSError when it is not built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise OSError(
+                f"{LIBPATH} not found: build the HIP module first (`make` or __graft_entry__.build()); "
+                "datum_amd has no CPU fallback"
+            )
+        lib = ctypes.CDLL(LIBPATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class OceanError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"datum_ocean error {code}: {message}")
+        self.code = code
+
+
+def _ptr(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(P)
+
+
+class Ocean:
+    """One handle of the C ABI (a device, a resolution, `cascades` independent grids)."""
+
+    def __init__(self, resolution, cascades=1, device=0):
+        self.lib = load()
+        self.N = resolution
+        self.cascades = cascades
+        self.device = device
+        h = P()
+        rc = self.lib.datum_ocean_create(ctypes.byref(h), device, resolution, cascades)
+        if rc != 0:
+            raise OceanError(rc, self.lib.datum_ocean_last_error(None).decode())
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise OceanError(rc, self.lib.datum_ocean_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.datum_ocean_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.datum_ocean_set_stream(self.h, P(stream_ptr) if stream_ptr else None))
+
+    def bind_maps(self, device_ptr, nbytes):
+        self._check(self.lib.datum_ocean_bind_maps(self.h, P(device_ptr) if device_ptr else None, nbytes))
+
+    def maps_device(self):
+        p = P()
+        n = ctypes.c_size_t()
+        self._check(self.lib.datum_ocean_maps_device(self.h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def set_cascade(self, cascade, wavescale, choppiness):
+        self._check(self.lib.datum_ocean_set_cascade(self.h, cascade, wavescale, choppiness))
+
+    def upload_state(self, cascade, h0, phase=None):
+        h0 = np.ascontiguousarray(h0, np.float32)
+        assert h0.size == 2 * self.N * self.N
+        if phase is not None:
+            phase = np.ascontiguousarray(phase, np.float32)
+            assert phase.size == self.N * self.N
+        self._check(self.lib.datum_ocean_upload_state(self.h, cascade, _ptr(h0), _ptr(phase) if phase is not None else None))
+
+    def read_state(self, cascade):
+        out = np.empty((self.N, self.N), np.float32)
+        self._check(self.lib.datum_ocean_read_state(self.h, cascade, _ptr(out)))
+        return out
+
+    def update(self, dt):
+        self._check(self.lib.datum_ocean_update(self.h, dt))
+
+    def displace(self):
+        self._check(self.lib.datum_ocean_displace(self.h))
+
+    def gen(self, cascade, oceanset, sizex, sizey, vertices_device_ptr):
+        self._check(self.lib.datum_ocean_gen(self.h, cascade, ctypes.byref(oceanset), sizex, sizey, P(vertices_device_ptr)))
+
+    def read_maps(self, cascade):
+        out = np.empty((2, self.N, self.N, 4), np.float32)
+        self._check(self.lib.datum_ocean_read_maps(self.h, cascade, _ptr(out)))
+        return out
+
+    def sync(self):
+        self._check(self.lib.datum_ocean_sync(self.h))
+
+    def debug_sim(self, cascade):
+        h, hx, hy = (np.empty((self.N, self.N, 2), np.float32) for _ in range(3))
+        self._check(self.lib.datum_ocean_debug_sim(self.h, cascade, _ptr(h), _ptr(hx), _ptr(hy)))
+        return h, hx, hy
+
+    def debug_rowpass(self, cascade):
+        h, hx, hy = (np.empty((self.N, self.N, 2), np.float32) for _ in range(3))
+        self._check(self.lib.datum_ocean_debug_rowpass(self.h, cascade, _ptr(h), _ptr(hx), _ptr(hy)))
+        return h, hx, hy
+
+    def profile_begin(self, max_steps):
+        self._check(self.lib.datum_ocean_profile_begin(self.h, max_steps))
+
+    def profile_end(self):
+        row, col, n = D(), D(), I()
+        self._check(self.lib.datum_ocean_profile_end(self.h, ctypes.byref(row), ctypes.byref(col), ctypes.byref(n)))
+        return row.value, col.value, n.value
+
+    def algorithmic_bytes(self):
+        row, col = D(), D()
+        self._check(self.lib.datum_ocean_algorithmic_bytes(self.h, ctypes.byref(row), ctypes.byref(col)))
+        return row.value, col.value
+
+
+def reference_weights(N):
+    stages = int(np.log2(N))
+    w = np.empty((N, 2 * stages), np.float32)
+    rc = load().datum_ocean_reference_weights(N, _ptr(w))
+    if rc != 0:
+        raise OceanError(rc, load().datum_ocean_last_error(None).decode())
+    return w

@@ -1,0 +1,759 @@
+// ocean_capi.hip -- the extern "C" module of include/datum_ocean_hip.h (host side of the HIP path).
+//
+// Owns the device buffers the reference keeps in OceanContext (src/renderer/ocean.h:12-46:
+// oceanset, spectrum, displacementmap) and enqueues the kernels of ocean_kernels.hip where the
+// reference records its five dispatches (src/renderer/ocean.cpp:769-793).
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ocean_kernels.hip"
+
+using namespace ocean;
+
+struct datum_ocean_ctx
+{
+  int device = 0;
+  int N = 0;
+  int cascades = 0;
+
+  hipStream_t stream = nullptr;       // the one in use
+  hipStream_t ownstream = nullptr;
+
+  float2 *h0 = nullptr;
+  float *phase = nullptr;
+  cf *spec = nullptr;
+  float4 *maps = nullptr;             // the one in use
+  float4 *ownmaps = nullptr;
+  cf *tw = nullptr;
+  cf *scratch = nullptr;              // 3 row-major planes for the debug read-backs (lazy)
+
+  CascadeConst casc[DATUM_OCEAN_MAX_CASCADES];
+  bool uploaded[DATUM_OCEAN_MAX_CASCADES] = {};
+
+  std::vector<float> pending;         // queued update_ocean dt's
+
+  hipEvent_t complete = nullptr;      // "rendercomplete"
+
+  // profiling
+  bool profiling = false;
+  int profmax = 0;
+  int profsteps = 0;
+  std::vector<hipEvent_t> events;     // 3 per step
+
+  std::string error;
+};
+
+namespace
+{
+  std::string g_error;   // errors without a handle
+
+  int fail(datum_ocean_ctx *ctx, int code, char const *what)
+  {
+    char buf[512];
+
+    if (code > 0)
+      snprintf(buf, sizeof(buf), "%s: %s (hipError %d)", what, hipGetErrorString((hipError_t)code), code);
+    else
+      snprintf(buf, sizeof(buf), "%s (code %d)", what, code);
+
+    (ctx ? ctx->error : g_error) = buf;
+
+    return code;
+  }
+
+  #define HIPCHECK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, (int)e_, #call); } while(0)
+
+  bool supported(int n)
+  {
+    return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096;
+  }
+
+  size_t plane(datum_ocean_ctx const *ctx) { return (size_t)ctx->N * ctx->N; }
+
+  StepArgs make_args(datum_ocean_ctx *ctx, int ndt, float const *dt)
+  {
+    StepArgs a;
+    a.h0 = ctx->h0;
+    a.phase = ctx->phase;
+    a.spec = ctx->spec;
+    a.maps = ctx->maps;
+    a.tw = ctx->tw;
+    a.ndt = ndt;
+    for(int i = 0; i < MAX_PENDING; ++i)
+      a.dt[i] = (i < ndt) ? dt[i] : 0.0f;
+    memcpy(a.casc, ctx->casc, sizeof(a.casc));
+    return a;
+  }
+
+  template<int N>
+  hipError_t configure()
+  {
+    hipError_t e;
+
+    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS);
+    if (e != hipSuccess)
+      return e;
+
+    return hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
+  }
+
+  template<int N>
+  void launch_rowpass(datum_ocean_ctx *ctx, StepArgs const &a)
+  {
+    dim3 grid(N / RowCfg<N>::ROWS, ctx->cascades);
+
+    hipLaunchKernelGGL(ocean_rowpass_kernel<N>, grid, dim3(RowCfg<N>::THREADS), RowCfg<N>::LDS, ctx->stream, a);
+  }
+
+  template<int N>
+  void launch_colpass(datum_ocean_ctx *ctx, StepArgs const &a)
+  {
+    dim3 grid(N / ColCfg<N>::W, ctx->cascades);
+
+    hipLaunchKernelGGL(ocean_colpass_kernel<N>, grid, dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, ctx->stream, a);
+  }
+
+  #define DISPATCH_N(n, expr) \
+    switch(n) { \
+      case 64: { constexpr int NN = 64; expr; } break; \
+      case 128: { constexpr int NN = 128; expr; } break; \
+      case 256: { constexpr int NN = 256; expr; } break; \
+      case 512: { constexpr int NN = 512; expr; } break; \
+      case 1024: { constexpr int NN = 1024; expr; } break; \
+      case 2048: { constexpr int NN = 2048; expr; } break; \
+      case 4096: { constexpr int NN = 4096; expr; } break; \
+    }
+
+  // flush queued updates that do not fit into one displace call
+  int flush_pending(datum_ocean_ctx *ctx, size_t keep)
+  {
+    while (ctx->pending.size() > keep)
+    {
+      int n = (int)std::min<size_t>(MAX_PENDING, ctx->pending.size() - keep);
+
+      StepArgs a = make_args(ctx, n, ctx->pending.data());
+
+      dim3 grid(1024, ctx->cascades);
+      hipLaunchKernelGGL(ocean_advance_kernel, grid, dim3(256), 0, ctx->stream, a, ctx->N);
+      HIPCHECK(ctx, hipGetLastError());
+
+      ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + n);
+    }
+
+    return DATUM_OCEAN_OK;
+  }
+
+  int ensure_scratch(datum_ocean_ctx *ctx)
+  {
+    if (!ctx->scratch)
+      HIPCHECK(ctx, hipMalloc(&ctx->scratch, 3 * plane(ctx) * sizeof(cf)));
+
+    return DATUM_OCEAN_OK;
+  }
+}
+
+extern "C"
+{
+
+int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int cascades)
+{
+  if (!out)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_create: null out pointer");
+
+  *out = nullptr;
+
+  if (!supported(resolution))
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_create: resolution must be a power of two in [64, 4096]");
+
+  if (cascades < 1 || cascades > DATUM_OCEAN_MAX_CASCADES)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_create: cascades out of range");
+
+  HIPCHECK(nullptr, hipSetDevice(device));
+
+  datum_ocean_ctx *ctx = new (std::nothrow) datum_ocean_ctx;
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_ENOMEM, "datum_ocean_create: out of host memory");
+
+  ctx->device = device;
+  ctx->N = resolution;
+  ctx->cascades = cascades;
+
+  size_t const P = plane(ctx);
+
+  #define CREATECHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int rc_ = fail(nullptr, (int)e_, #call); datum_ocean_destroy(ctx); return rc_; } } while(0)
+
+  CREATECHECK(hipStreamCreateWithFlags(&ctx->ownstream, hipStreamNonBlocking));
+  ctx->stream = ctx->ownstream;
+
+  CREATECHECK(hipMalloc(&ctx->h0, cascades * P * sizeof(float2)));
+  CREATECHECK(hipMalloc(&ctx->phase, cascades * P * sizeof(float)));
+  CREATECHECK(hipMalloc(&ctx->spec, cascades * 3 * P * sizeof(cf)));
+  CREATECHECK(hipMalloc(&ctx->ownmaps, cascades * 2 * P * sizeof(float4)));
+  CREATECHECK(hipMalloc(&ctx->tw, resolution * sizeof(cf)));
+  ctx->maps = ctx->ownmaps;
+
+  CREATECHECK(hipMemsetAsync(ctx->h0, 0, cascades * P * sizeof(float2), ctx->stream));
+  CREATECHECK(hipMemsetAsync(ctx->phase, 0, cascades * P * sizeof(float), ctx->stream));
+  CREATECHECK(hipMemsetAsync(ctx->ownmaps, 0, cascades * 2 * P * sizeof(float4), ctx->stream));
+
+  // exp(+2 pi i k / N), rounded once from double (the reference's table -- ocean.cpp:686-700 -- is per
+  // lane and stage and evaluated at unreduced fp32 angles; see datum_ocean_reference_weights)
+  std::vector<cf> tw(resolution);
+  for(int k = 0; k < resolution; ++k)
+  {
+    double ang = 2.0 * 3.14159265358979323846 * k / resolution;
+    tw[k] = cf{ (float)std::cos(ang), (float)std::sin(ang) };
+  }
+  // exact values on the axes and diagonals
+  tw[0] = cf{ 1.0f, 0.0f };
+  tw[resolution/4] = cf{ 0.0f, 1.0f };
+  tw[resolution/2] = cf{ -1.0f, 0.0f };
+  tw[3*resolution/4] = cf{ 0.0f, -1.0f };
+
+  CREATECHECK(hipMemcpy(ctx->tw, tw.data(), resolution * sizeof(cf), hipMemcpyHostToDevice));
+
+  for(int c = 0; c < DATUM_OCEAN_MAX_CASCADES; ++c)
+  {
+    // OceanParams defaults (ocean.h:60,64)
+    ctx->casc[c].wavescale = 64.0f;
+    ctx->casc[c].scale = 1 / 64.0f;
+    ctx->casc[c].choppiness = 1.35f;
+    ctx->casc[c].nz = 4 / (ctx->casc[c].scale * resolution);
+  }
+
+  hipError_t ce = hipSuccess;
+  DISPATCH_N(resolution, ce = configure<NN>());
+  CREATECHECK(ce);
+
+  CREATECHECK(hipStreamSynchronize(ctx->stream));
+
+  #undef CREATECHECK
+
+  *out = ctx;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_destroy(datum_ocean_t ctx)
+{
+  if (!ctx)
+    return DATUM_OCEAN_OK;
+
+  (void)hipSetDevice(ctx->device);
+
+  if (ctx->stream)
+    (void)hipStreamSynchronize(ctx->stream);
+
+  for(hipEvent_t e : ctx->events)
+    (void)hipEventDestroy(e);
+
+  if (ctx->complete)
+    (void)hipEventDestroy(ctx->complete);
+
+  (void)hipFree(ctx->h0);
+  (void)hipFree(ctx->phase);
+  (void)hipFree(ctx->spec);
+  (void)hipFree(ctx->ownmaps);
+  (void)hipFree(ctx->tw);
+  (void)hipFree(ctx->scratch);
+
+  if (ctx->ownstream)
+    (void)hipStreamDestroy(ctx->ownstream);
+
+  delete ctx;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_set_stream: null handle");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownstream;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_bind_maps(datum_ocean_t ctx, void *device_ptr, size_t bytes)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_bind_maps: null handle");
+
+  size_t need = ctx->cascades * 2 * plane(ctx) * sizeof(float4);
+
+  if (device_ptr && bytes < need)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_bind_maps: buffer smaller than cascades*2*N*N*16 bytes");
+
+  if (device_ptr && ((uintptr_t)device_ptr & 15))
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_bind_maps: buffer must be 16-byte aligned");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  ctx->maps = device_ptr ? (float4*)device_ptr : ctx->ownmaps;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_maps_device(datum_ocean_t ctx, void **device_ptr, size_t *bytes)
+{
+  if (!ctx || !device_ptr)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_maps_device: null argument");
+
+  *device_ptr = ctx->maps;
+
+  if (bytes)
+    *bytes = ctx->cascades * 2 * plane(ctx) * sizeof(float4);
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, float choppiness)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_set_cascade: null handle");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_set_cascade: cascade out of range");
+
+  if (!(wavescale > 0))
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_set_cascade: wavescale must be positive");
+
+  // queued updates were issued under the old wavescale: apply them first
+  if (wavescale != ctx->casc[cascade].wavescale && !ctx->pending.empty())
+  {
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    int rc = flush_pending(ctx, 0);
+    if (rc != DATUM_OCEAN_OK)
+      return rc;
+  }
+
+  CascadeConst &cc = ctx->casc[cascade];
+
+  cc.wavescale = wavescale;
+  cc.scale = 1 / wavescale;                      // ocean.cpp:743
+  cc.choppiness = choppiness;                    // ocean.cpp:744
+  cc.nz = 4 / (cc.scale * ctx->N);               // ocean.map.comp:77
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, float const *phase)
+{
+  if (!ctx || !h0)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_upload_state: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_upload_state: cascade out of range");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  // the new state replaces the old one: updates queued against the old state are applied first so that
+  // the other cascades keep them
+  int rc = flush_pending(ctx, 0);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  size_t const P = plane(ctx);
+
+  HIPCHECK(ctx, hipMemcpyAsync(ctx->h0 + cascade * P, h0, P * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+
+  if (phase)
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->phase + cascade * P, phase, P * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  else
+    HIPCHECK(ctx, hipMemsetAsync(ctx->phase + cascade * P, 0, P * sizeof(float), ctx->stream));
+
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));   // the host buffers are the caller's again
+
+  ctx->uploaded[cascade] = true;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_read_state(datum_ocean_t ctx, int cascade, float *phase)
+{
+  if (!ctx || !phase)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_read_state: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_read_state: cascade out of range");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  int rc = flush_pending(ctx, 0);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  size_t const P = plane(ctx);
+
+  HIPCHECK(ctx, hipMemcpyAsync(phase, ctx->phase + cascade * P, P * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_update(datum_ocean_t ctx, float dt)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_update: null handle");
+
+  ctx->pending.push_back(dt);
+
+  if (ctx->pending.size() > 4 * MAX_PENDING)
+  {
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    return flush_pending(ctx, MAX_PENDING);
+  }
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_displace(datum_ocean_t ctx)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_displace: null handle");
+
+  for(int c = 0; c < ctx->cascades; ++c)
+    if (!ctx->uploaded[c])
+      return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_displace: a cascade has no state (datum_ocean_upload_state)");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  int rc = flush_pending(ctx, MAX_PENDING);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  StepArgs a = make_args(ctx, (int)ctx->pending.size(), ctx->pending.data());
+  ctx->pending.clear();
+
+  bool const prof = ctx->profiling && ctx->profsteps < ctx->profmax;
+  hipEvent_t *ev = prof ? &ctx->events[3 * ctx->profsteps] : nullptr;
+
+  if (prof)
+    HIPCHECK(ctx, hipEventRecord(ev[0], ctx->stream));
+
+  DISPATCH_N(ctx->N, launch_rowpass<NN>(ctx, a));
+  HIPCHECK(ctx, hipGetLastError());
+
+  if (prof)
+    HIPCHECK(ctx, hipEventRecord(ev[1], ctx->stream));
+
+  DISPATCH_N(ctx->N, launch_colpass<NN>(ctx, a));
+  HIPCHECK(ctx, hipGetLastError());
+
+  if (prof)
+  {
+    HIPCHECK(ctx, hipEventRecord(ev[2], ctx->stream));
+    ctx->profsteps += 1;
+  }
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, int sizex, int sizey, void *vertices_device)
+{
+  if (!ctx || !set || !vertices_device)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_gen: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_gen: cascade out of range");
+
+  if (sizex < 2 || sizey < 2)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_gen: mesh must be at least 2 x 2");
+
+  if ((uintptr_t)vertices_device & 15)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_gen: vertex buffer must be 16-byte aligned");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  GenArgs g;
+  g.set = *set;
+  g.layer0 = ctx->maps + (size_t)cascade * 2 * plane(ctx);
+  g.layer1 = g.layer0 + plane(ctx);
+  g.N = ctx->N;
+  g.sizex = sizex;
+  g.sizey = sizey;
+  g.vertices = (float*)vertices_device;
+
+  dim3 grid((sizex + 15) / 16, (sizey + 15) / 16);
+
+  hipLaunchKernelGGL(ocean_gen_kernel, grid, dim3(256), 0, ctx->stream, g);
+  HIPCHECK(ctx, hipGetLastError());
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps)
+{
+  if (!ctx || !maps)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_read_maps: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_read_maps: cascade out of range");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  size_t const P = plane(ctx);
+
+  HIPCHECK(ctx, hipMemcpyAsync(maps, ctx->maps + (size_t)cascade * 2 * P, 2 * P * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_sync(datum_ocean_t ctx)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_sync: null handle");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_wait_event(datum_ocean_t ctx, void *hip_event)
+{
+  if (!ctx || !hip_event)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_wait_event: null argument");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)hip_event, 0));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_signal(datum_ocean_t ctx, void **hip_event)
+{
+  if (!ctx || !hip_event)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_signal: null argument");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  if (!ctx->complete)
+    HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->complete, hipEventDisableTiming));
+
+  HIPCHECK(ctx, hipEventRecord(ctx->complete, ctx->stream));
+
+  *hip_event = ctx->complete;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_device_alloc(datum_ocean_t ctx, size_t bytes, void **device_ptr)
+{
+  if (!ctx || !device_ptr || bytes == 0)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_device_alloc: bad argument");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipMalloc(device_ptr, bytes));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_device_free(datum_ocean_t ctx, void *device_ptr)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_device_free: null handle");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHECK(ctx, hipFree(device_ptr));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_device_write(datum_ocean_t ctx, void *device_dst, void const *host_src, size_t bytes)
+{
+  if (!ctx || !device_dst || !host_src)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_device_write: null argument");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_device_read(datum_ocean_t ctx, void *host_dst, void const *device_src, size_t bytes)
+{
+  if (!ctx || !host_dst || !device_src)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_device_read: null argument");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  return DATUM_OCEAN_OK;
+}
+
+char const *datum_ocean_last_error(datum_ocean_t ctx)
+{
+  return ctx ? ctx->error.c_str() : g_error.c_str();
+}
+
+int datum_ocean_reference_weights(int resolution, float *weights)
+{
+  if (!supported(resolution) || !weights)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_reference_weights: bad argument");
+
+  int stages = 0;
+  while ((1 << stages) < resolution)
+    ++stages;
+
+  float const pi = 3.14159265358979323846f;
+
+  // lane i, stage n: angle = -2 pi i / 2^(n+1), all in fp32 as the reference evaluates it
+  for(int i = 0; i < resolution; ++i)
+  {
+    float *row = weights + (size_t)i * 2 * stages;
+
+    for(int n = 0; n < stages; ++n)
+    {
+      float angle = -2 * pi * i / (2 * powf(2.0f, (float)n));
+
+      row[2*n+0] = cosf(angle);
+      row[2*n+1] = sinf(angle);
+    }
+  }
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_debug_sim(datum_ocean_t ctx, int cascade, float *h, float *hx, float *hy)
+{
+  if (!ctx || !h || !hx || !hy)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_debug_sim: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_debug_sim: cascade out of range");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  int rc = flush_pending(ctx, 0);
+  if (rc == DATUM_OCEAN_OK)
+    rc = ensure_scratch(ctx);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  size_t const P = plane(ctx);
+
+  StepArgs a = make_args(ctx, 0, nullptr);
+
+  hipLaunchKernelGGL(ocean_sim_kernel, dim3(1024), dim3(256), 0, ctx->stream, a, ctx->N, cascade, ctx->scratch, ctx->scratch + P, ctx->scratch + 2 * P);
+  HIPCHECK(ctx, hipGetLastError());
+
+  HIPCHECK(ctx, hipMemcpyAsync(h, ctx->scratch, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipMemcpyAsync(hx, ctx->scratch + P, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipMemcpyAsync(hy, ctx->scratch + 2 * P, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *h, float *hx, float *hy)
+{
+  if (!ctx || !h || !hx || !hy)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_debug_rowpass: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_debug_rowpass: cascade out of range");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  int rc = ensure_scratch(ctx);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  size_t const P = plane(ctx);
+
+  float *dst[3] = { h, hx, hy };
+
+  for(int f = 0; f < 3; ++f)
+  {
+    hipLaunchKernelGGL(ocean_unblock_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->spec + ((size_t)cascade * 3 + f) * P, ctx->N, ctx->scratch + f * P);
+    HIPCHECK(ctx, hipGetLastError());
+    HIPCHECK(ctx, hipMemcpyAsync(dst[f], ctx->scratch + f * P, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
+  }
+
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_profile_begin(datum_ocean_t ctx, int max_steps)
+{
+  if (!ctx || max_steps < 1)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_profile_begin: bad argument");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  while ((int)ctx->events.size() < 3 * max_steps)
+  {
+    hipEvent_t e;
+    HIPCHECK(ctx, hipEventCreate(&e));
+    ctx->events.push_back(e);
+  }
+
+  ctx->profiling = true;
+  ctx->profmax = max_steps;
+  ctx->profsteps = 0;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_profile_end(datum_ocean_t ctx, double *rowpass_ms, double *colpass_ms, int *steps)
+{
+  if (!ctx || !ctx->profiling)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_profile_end: profiling was not started");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  double row = 0, col = 0;
+
+  for(int i = 0; i < ctx->profsteps; ++i)
+  {
+    float ms;
+    HIPCHECK(ctx, hipEventElapsedTime(&ms, ctx->events[3*i+0], ctx->events[3*i+1]));
+    row += ms;
+    HIPCHECK(ctx, hipEventElapsedTime(&ms, ctx->events[3*i+1], ctx->events[3*i+2]));
+    col += ms;
+  }
+
+  int n = ctx->profsteps;
+
+  if (rowpass_ms) *rowpass_ms = n ? row / n : 0.0;
+  if (colpass_ms) *colpass_ms = n ? col / n : 0.0;
+  if (steps) *steps = n;
+
+  ctx->profiling = false;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_algorithmic_bytes(datum_ocean_t ctx, double *rowpass_bytes, double *colpass_bytes)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_algorithmic_bytes: null handle");
+
+  double pts = (double)plane(ctx) * ctx->cascades;
+
+  // h0 8 + phase in 4 + phase out 4 + spectrum out 24 | spectrum in 24 + two RGBA32F layers 32
+  if (rowpass_bytes) *rowpass_bytes = 40.0 * pts;
+  if (colpass_bytes) *colpass_bytes = 56.0 * pts;
+
+  return DATUM_OCEAN_OK;
+}
+
+}

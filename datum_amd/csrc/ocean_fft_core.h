@@ -1,0 +1,300 @@
+// ocean_fft_core.h -- register-resident mixed-radix Stockham inverse FFT of one line.
+//
+// Replaces the radix-2, log2(N)-barrier LDS ping-pong of data/ocean.fftx.comp:55-99 /
+// ocean.ffty.comp:55-99 (one butterfly per thread per stage, two global twiddle loads per
+// stage) by at most three passes: every thread keeps E = 4/8/16 points of the line in VGPRs,
+// does a radix-E butterfly in registers, and only exchanges through LDS between passes.
+// The transform computed is the same one: out[n] = sum_k in[k] exp(+2 pi i k n / N)
+// (= N * IFFT, natural order in and out: conj -> forward -> conj of fftx.comp:60-62,97-99).
+//
+// Line layout while in registers: thread t (0 <= t < T = N/E) holds element t + T*s in slot s,
+// both before pass 0 and after the last pass.
+//
+// The file is host/device neutral so the index arithmetic can be exercised on a CPU by
+// emulating the T threads of a line (tests/cpu/fft_core_emul.cpp); kernels live in
+// ocean_kernels.hip.
+
+#pragma once
+
+#if defined(__HIPCC__)
+#define OC_HD __host__ __device__ __forceinline__
+#define OC_UNROLL _Pragma("unroll")
+#else
+#define OC_HD inline
+#define OC_UNROLL
+#endif
+
+namespace ocean
+{
+  struct alignas(8) cf
+  {
+    float x, y;
+  };
+
+  OC_HD cf operator+(cf a, cf b) { return { a.x + b.x, a.y + b.y }; }
+  OC_HD cf operator-(cf a, cf b) { return { a.x - b.x, a.y - b.y }; }
+
+  OC_HD float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+  // a * b
+  OC_HD cf cmul(cf a, cf b) { return { fmaf_(a.x, b.x, -(a.y * b.y)), fmaf_(a.x, b.y, a.y * b.x) }; }
+
+  // i * a
+  OC_HD cf muli(cf a) { return { -a.y, a.x }; }
+
+  //|---------------------- plan ----------------------------------------------
+
+  constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
+
+  // N = E^(NP-1) * RL: NP-1 passes of radix E, one last pass of radix RL <= E done as M = E/RL tasks
+  template<int N>
+  struct Plan
+  {
+    static_assert(N == 64 || N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096, "unsupported resolution");
+
+    static constexpr int E = (N == 64) ? 4 : (N == 128 || N == 512) ? 8 : 16;
+    static constexpr int T = N / E;
+    static constexpr int NP = (N == 256) ? 2 : 3;
+    static constexpr int RL = N / ipow(E, NP - 1);
+    static constexpr int M = E / RL;
+    static constexpr int NS_LAST = N / RL;      // product of the radices before the last pass
+    static constexpr int LINE = N + N / 16;     // padded LDS line length, in complex elements
+
+    static_assert(RL >= 2 && RL <= E && E % RL == 0, "bad plan");
+  };
+
+  // LDS index padding: one extra element every 16, breaks the power-of-two strides of the pass-0 stores
+  OC_HD constexpr int padidx(int i) { return i + (i >> 4); }
+
+  //|---------------------- radix butterflies ---------------------------------
+  // idft<R>: v[q] <- sum_r v[r] exp(+2 pi i q r / R), natural order
+
+  OC_HD void idft2(cf &a, cf &b)
+  {
+    cf s = a + b, d = a - b;
+    a = s;
+    b = d;
+  }
+
+  OC_HD void idft4(cf &a0, cf &a1, cf &a2, cf &a3)
+  {
+    cf s02 = a0 + a2, d02 = a0 - a2;
+    cf s13 = a1 + a3, d13 = muli(a1 - a3);
+
+    a0 = s02 + s13;
+    a1 = d02 + d13;
+    a2 = s02 - s13;
+    a3 = d02 - d13;
+  }
+
+  template<int R> struct Radix;
+
+  template<> struct Radix<2>
+  {
+    static OC_HD void run(cf (&v)[2]) { idft2(v[0], v[1]); }
+  };
+
+  template<> struct Radix<4>
+  {
+    static OC_HD void run(cf (&v)[4]) { idft4(v[0], v[1], v[2], v[3]); }
+  };
+
+  template<> struct Radix<8>
+  {
+    static OC_HD void run(cf (&v)[8])
+    {
+      const float h = 0.70710678118654752440f;
+
+      // index = a + 2b: 4-point transforms over b for a = 0, 1
+      idft4(v[0], v[2], v[4], v[6]);
+      idft4(v[1], v[3], v[5], v[7]);
+
+      // t[1][c] *= exp(2 pi i c / 8)
+      cf t1 = { (v[3].x - v[3].y) * h, (v[3].x + v[3].y) * h };
+      cf t2 = muli(v[5]);
+      cf t3 = { (-v[7].x - v[7].y) * h, (v[7].x - v[7].y) * h };
+
+      cf o[8];
+      o[0] = v[0] + v[1];  o[4] = v[0] - v[1];
+      o[1] = v[2] + t1;    o[5] = v[2] - t1;
+      o[2] = v[4] + t2;    o[6] = v[4] - t2;
+      o[3] = v[6] + t3;    o[7] = v[6] - t3;
+
+      OC_UNROLL
+      for(int i = 0; i < 8; ++i)
+        v[i] = o[i];
+    }
+  };
+
+  template<> struct Radix<16>
+  {
+    static OC_HD void run(cf (&v)[16])
+    {
+      const float h = 0.70710678118654752440f;
+      const float c1 = 0.92387953251128675613f;   // cos(pi/8)
+      const float s1 = 0.38268343236508977173f;   // sin(pi/8)
+
+      // index = a + 4b: 4-point transforms over b for a = 0..3; slot a + 4c then holds t[a][c]
+      idft4(v[0], v[4], v[8], v[12]);
+      idft4(v[1], v[5], v[9], v[13]);
+      idft4(v[2], v[6], v[10], v[14]);
+      idft4(v[3], v[7], v[11], v[15]);
+
+      // t[a][c] *= exp(2 pi i a c / 16)
+      v[5] = cmul(v[5], cf{ c1, s1 });                                          // a=1 c=1 : w^1
+      v[9] = cf{ (v[9].x - v[9].y) * h, (v[9].x + v[9].y) * h };                // a=1 c=2 : w^2
+      v[13] = cmul(v[13], cf{ s1, c1 });                                        // a=1 c=3 : w^3
+      v[6] = cf{ (v[6].x - v[6].y) * h, (v[6].x + v[6].y) * h };                // a=2 c=1 : w^2
+      v[10] = muli(v[10]);                                                      // a=2 c=2 : w^4
+      v[14] = cf{ (-v[14].x - v[14].y) * h, (v[14].x - v[14].y) * h };          // a=2 c=3 : w^6
+      v[7] = cmul(v[7], cf{ s1, c1 });                                          // a=3 c=1 : w^3
+      v[11] = cf{ (-v[11].x - v[11].y) * h, (v[11].x - v[11].y) * h };          // a=3 c=2 : w^6
+      v[15] = cmul(v[15], cf{ -c1, -s1 });                                      // a=3 c=3 : w^9
+
+      // 4-point transforms over a for each c; output q = c + 4d
+      cf o[16];
+      OC_UNROLL
+      for(int c = 0; c < 4; ++c)
+      {
+        cf x0 = v[4*c+0], x1 = v[4*c+1], x2 = v[4*c+2], x3 = v[4*c+3];
+        idft4(x0, x1, x2, x3);
+        o[c] = x0;
+        o[c+4] = x1;
+        o[c+8] = x2;
+        o[c+12] = x3;
+      }
+
+      OC_UNROLL
+      for(int i = 0; i < 16; ++i)
+        v[i] = o[i];
+    }
+  };
+
+  // powers w^1 .. w^(R-1) of a unit twiddle by a product tree of depth <= 4
+  template<int R>
+  OC_HD void twiddle_powers(cf w1, cf (&w)[R])
+  {
+    w[0] = cf{ 1.0f, 0.0f };
+    w[1] = w1;
+    if (R > 2)
+    {
+      w[2] = cmul(w1, w1);
+      w[3] = cmul(w[2], w1);
+    }
+    if (R > 4)
+    {
+      w[4] = cmul(w[2], w[2]);
+      w[5] = cmul(w[4], w1);
+      w[6] = cmul(w[4], w[2]);
+      w[7] = cmul(w[4], w[3]);
+    }
+    if (R > 8)
+    {
+      w[8] = cmul(w[4], w[4]);
+      OC_UNROLL
+      for(int i = 1; i < 8; ++i)
+        w[8+i] = cmul(w[8], w[i]);
+    }
+  }
+
+  //|---------------------- one line ------------------------------------------
+  // tw[k] = exp(+2 pi i k / N), k < N   (built in double on the host: ocean_capi)
+  // `line` points at this line's padded LDS region (Plan::LINE elements)
+
+  template<int N>
+  struct LineFFT
+  {
+    typedef Plan<N> P;
+
+    static constexpr int E = P::E;
+    static constexpr int T = P::T;
+    static constexpr int RL = P::RL;
+    static constexpr int M = P::M;
+
+    // per-thread twiddles kept in registers: the last pass (Ns = N / RL) needs w1 = exp(2 pi i j / N)
+    // for its tasks j = t + T m; higher powers come from twiddle_powers
+    struct Twiddles
+    {
+      cf last[M];
+    };
+
+    static OC_HD void load_twiddles(cf const *tw, int t, Twiddles &w)
+    {
+      OC_UNROLL
+      for(int m = 0; m < M; ++m)
+        w.last[m] = tw[((t + T * m) % P::NS_LAST) * (N / (P::NS_LAST * RL))];
+    }
+
+    // middle pass (Ns = E) twiddles, shared by every line: midtab[r E + a] = exp(2 pi i a r / E^2),
+    // a = t % E fastest so that a wave reads 16 consecutive entries per r.  E*E entries (in LDS).
+    static constexpr int MIDTAB = (P::NP == 3) ? E * E : 0;
+
+    static OC_HD cf midtab_entry(cf const *tw, int i)
+    {
+      int a = i % E, r = i / E;
+
+      return tw[(a * r * (N / (E * E))) % N];
+    }
+
+    // pass 0: Ns = 1, radix E, task j = t.  v[s] = x[t + T s] -> line[t E + q]
+    static OC_HD void pass0(cf (&v)[E], int t, cf *line)
+    {
+      Radix<E>::run(v);
+
+      OC_UNROLL
+      for(int q = 0; q < E; ++q)
+        line[padidx(t * E + q)] = v[q];
+    }
+
+    // middle pass (NP == 3): Ns = E, radix E, task j = t.  load + twiddle + butterfly
+    static OC_HD void mid_load(cf (&v)[E], int t, cf const *line, cf const *midtab)
+    {
+      OC_UNROLL
+      for(int r = 0; r < E; ++r)
+        v[r] = line[padidx(t + T * r)];
+
+      OC_UNROLL
+      for(int r = 1; r < E; ++r)
+        v[r] = cmul(v[r], midtab[r * E + (t % E)]);
+
+      Radix<E>::run(v);
+    }
+
+    static OC_HD void mid_store(cf const (&v)[E], int t, cf *line)
+    {
+      int base = (t / E) * E * E + (t % E);
+
+      OC_UNROLL
+      for(int q = 0; q < E; ++q)
+        line[padidx(base + q * E)] = v[q];
+    }
+
+    // last pass: Ns = N/RL, radix RL, tasks j = t + T m.  result slot m + q M holds X[t + T (m + q M)]
+    static OC_HD void last(cf (&v)[E], int t, cf const *line, Twiddles const &w)
+    {
+      OC_UNROLL
+      for(int m = 0; m < M; ++m)
+      {
+        int j = t + T * m;
+
+        cf u[RL];
+        OC_UNROLL
+        for(int r = 0; r < RL; ++r)
+          u[r] = line[padidx(j + r * (N / RL))];
+
+        cf p[RL];
+        twiddle_powers<RL>(w.last[m], p);
+
+        OC_UNROLL
+        for(int r = 1; r < RL; ++r)
+          u[r] = cmul(u[r], p[r]);
+
+        Radix<RL>::run(u);
+
+        OC_UNROLL
+        for(int q = 0; q < RL; ++q)
+          v[m + q * M] = u[q];
+      }
+    }
+  };
+}

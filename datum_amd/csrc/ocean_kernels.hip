@@ -1,0 +1,633 @@
+// ocean_kernels.hip -- gfx950 kernels of the ocean displacement step and mesh generation.
+//
+// What the reference does in five Vulkan dispatches plus a host loop (src/renderer/ocean.cpp:217-236,
+// :769-793) is done here in two fused kernels (+ gen):
+//
+//   row pass    update_ocean phase advance (ocean.cpp:223-233) + ocean.sim (data/ocean.sim.comp:44-79)
+//               + ocean.fftx (data/ocean.fftx.comp:49-100), one wave64-sized thread group per row
+//               reads  h0 (8 B/pt, plus its mirror row through L2), phase (4)   writes phase (4), spectrum (24)
+//   column pass ocean.ffty (data/ocean.ffty.comp:49-100) + ocean.map (data/ocean.map.comp:51-82),
+//               one workgroup per 8-column tile          reads spectrum (24)    writes 2 x RGBA32F (32)
+//
+// = 96 algorithmic bytes per grid point against the reference's 196.
+//
+// Work spectrum layout (private to these kernels): per cascade and field, 8 x 8 blocks of complex
+// values, [y/8][x/8][y%8][x%8].  A row-pass workgroup (8 rows) writes one fully contiguous
+// 8*N*8-byte run per field; a column-pass wave reads one 512-byte block per load instruction.
+//
+// Built with -ffp-contract=off: products and sums are rounded as written (the phase state is
+// bit-identical to the host formula); the FFT butterflies ask for their FMAs explicitly.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ocean_fft_core.h"
+#include "../../include/datum_ocean_hip.h"
+
+namespace ocean
+{
+  constexpr int MAX_PENDING = 8;
+
+  struct CascadeConst
+  {
+    float wavescale;     // OceanParams::wavescale                 (update_ocean, ocean.cpp:225-229)
+    float scale;         // OceanSet::scale = 1 / wavescale        (ocean.cpp:743)
+    float choppiness;    // OceanSet::choppiness                   (ocean.cpp:744)
+    float nz;            // 4 / (scale * N)                        (ocean.map.comp:77)
+  };
+
+  struct StepArgs
+  {
+    float2 const *h0;    // [cascade][N*N]       OceanSet::h0
+    float *phase;        // [cascade][N*N]       OceanSet::phase
+    cf *spec;            // [cascade][3][N*N]    Spectrum::h, hx, hy (blocked layout)
+    float4 *maps;        // [cascade][2][N*N]    displacementmap, 2 layers RGBA32F
+    cf const *tw;        // [N]                  exp(+2 pi i k / N)
+    int ndt;
+    float dt[MAX_PENDING];
+    CascadeConst casc[DATUM_OCEAN_MAX_CASCADES];
+  };
+
+  template<int N>
+  __host__ __device__ __forceinline__ size_t blocked(int y, int x)
+  {
+    return ((size_t)((y >> 3) * (N / 8) + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7);
+  }
+
+  //|---------------------- update_ocean --------------------------------------
+
+  // dispersion(k) of ocean.cpp:82-87 at grid point (n, m), k as update_ocean forms it (ocean.cpp:225,229)
+  __device__ __forceinline__ float dispersion_at(int n, int m, int N, float wavescale)
+  {
+    float x = (6.2831855f * ((float)n - 0.5f * (float)N)) / wavescale;
+    float y = (6.2831855f * ((float)m - 0.5f * (float)N)) / wavescale;
+
+    float k2 = x * x + y * y;
+
+    return sqrtf((9.81f * sqrtf(k2)) * (1.0f + k2 / 136900.0f));
+  }
+
+  // fmod(phase + w*dt, 2 pi) of ocean.cpp:231.  fmod is exact; for 2pi <= a < 4pi it is a - 2pi (exact, Sterbenz)
+  __device__ __forceinline__ float advance_phase(float phase, float wdt)
+  {
+    const float twopi = 6.2831855f;
+
+    float a = phase + wdt;
+
+    if (a >= 0.0f && a < twopi)
+      return a;
+
+    if (a >= twopi && a < 2.0f * twopi)
+      return a - twopi;
+
+    return fmodf(a, twopi);
+  }
+
+  //|---------------------- ocean.sim -----------------------------------------
+
+  // one point of data/ocean.sim.comp:52-66: h~ from h0(k), h0 at the mirror index and the phase
+  __device__ __forceinline__ cf sim_height(float2 h0k, float2 h0mk, float phase)
+  {
+    float sin_v, cos_v;
+    sincosf(phase, &sin_v, &cos_v);
+
+    cf h;
+    h.x = (h0k.x + h0mk.x) * cos_v - (h0k.y + h0mk.y) * sin_v;
+    h.y = (h0k.x - h0mk.x) * sin_v + (h0k.y - h0mk.y) * cos_v;
+
+    return h;
+  }
+
+  // k of sim.comp:52 and its normalisation (sim.comp:54)
+  __device__ __forceinline__ float wavevector(int i, int N, float scale)
+  {
+    return (6.2831855f * ((float)i - 0.5f * (float)N)) * scale;
+  }
+
+  __device__ __forceinline__ float2 knorm_of(float kx, float ky)
+  {
+    float k2 = kx * kx + ky * ky;
+    float inv = (k2 != 0.0f) ? rsqrtf(k2) : 0.0f;
+
+    return make_float2(kx * inv, ky * inv);
+  }
+
+  //|---------------------- line FFT with workgroup barriers ------------------
+
+  template<int N>
+  __device__ __forceinline__ void fft_line(cf (&v)[Plan<N>::E], int t, cf *line, cf const *midtab, typename LineFFT<N>::Twiddles const &w, bool active)
+  {
+    typedef LineFFT<N> L;
+
+    if (active)
+      L::pass0(v, t, line);
+
+    __syncthreads();
+
+    if (Plan<N>::NP == 3)
+    {
+      if (active)
+        L::mid_load(v, t, line, midtab);
+
+      __syncthreads();
+
+      if (active)
+        L::mid_store(v, t, line);
+
+      __syncthreads();
+    }
+
+    if (active)
+      L::last(v, t, line, w);
+
+    __syncthreads();
+  }
+
+  //|---------------------- row pass ------------------------------------------
+
+  template<int N>
+  struct RowCfg
+  {
+    static constexpr int T = Plan<N>::T;
+    static constexpr int ROWS = (512 / T) < 8 ? (512 / T) : 8;
+    static constexpr int THREADS = ROWS * T;
+    static constexpr int MINWAVES = 4;                                  // per SIMD: two 512-thread workgroups per CU
+    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)ROWS * Plan<N>::LINE) * sizeof(cf);
+  };
+
+  template<int N>
+  __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MINWAVES) ocean_rowpass_kernel(StepArgs a)
+  {
+    typedef Plan<N> P;
+    typedef LineFFT<N> L;
+
+    constexpr int E = P::E;
+    constexpr int T = P::T;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    int const cascade = blockIdx.y;
+    int const r = threadIdx.x / T;
+    int const t = threadIdx.x % T;
+    int const y = blockIdx.x * RowCfg<N>::ROWS + r;
+
+    cf *midtab = reinterpret_cast<cf*>(smem);
+    cf *line = midtab + L::MIDTAB + r * P::LINE;
+
+    for(int i = threadIdx.x; i < L::MIDTAB; i += RowCfg<N>::THREADS)
+      midtab[i] = L::midtab_entry(a.tw, i);
+
+    CascadeConst const cc = a.casc[cascade];
+
+    size_t const plane = (size_t)N * N;
+
+    float2 const *h0 = a.h0 + cascade * plane;
+    float *phase = a.phase + cascade * plane;
+    cf *spec = a.spec + cascade * 3 * plane;
+
+    // ocean.sim for this row, CH points at a time to bound the registers in flight: this row of h0
+    // and phase, and the -k partner row read backwards (sim.comp:59: index (N-1-y, N-1-x)).
+    // update_ocean (ocean.cpp:223-233) is applied on the way, each pending dt in turn.
+    constexpr int CH = (E < 4) ? E : 4;
+
+    cf h[E];
+
+    #pragma unroll
+    for(int s0 = 0; s0 < E; s0 += CH)
+    {
+      float ph[CH];
+      float2 hk[CH], hm[CH];
+
+      #pragma unroll
+      for(int i = 0; i < CH; ++i)
+      {
+        int x = t + T * (s0 + i);
+
+        ph[i] = phase[(size_t)y * N + x];
+        hk[i] = h0[(size_t)y * N + x];
+        hm[i] = h0[(size_t)(N - 1 - y) * N + (N - 1 - x)];
+      }
+
+      if (a.ndt > 0)
+      {
+        #pragma unroll
+        for(int i = 0; i < CH; ++i)
+        {
+          int x = t + T * (s0 + i);
+
+          float omega = dispersion_at(x, y, N, cc.wavescale);
+
+          float p = ph[i];
+          for(int k = 0; k < a.ndt; ++k)
+            p = advance_phase(p, omega * a.dt[k]);
+
+          ph[i] = p;
+          phase[(size_t)y * N + x] = p;
+        }
+      }
+
+      #pragma unroll
+      for(int i = 0; i < CH; ++i)
+        h[s0 + i] = sim_height(hk[i], hm[i], ph[i]);
+
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    typename L::Twiddles w;
+    L::load_twiddles(a.tw, t, w);
+
+    // hx = -i h k^x, hy = -i h k^y (sim.comp:68-74), then h itself; each through the row transform
+    #pragma unroll
+    for(int field = 1; field <= 2; ++field)
+    {
+      // k^ is recomputed per field rather than kept across a transform (registers)
+      float ky = wavevector(y, N, cc.scale);
+      asm volatile("" : "+v"(ky));
+
+      cf v[E];
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+        float2 kn = knorm_of(wavevector(t + T * s, N, cc.scale), ky);
+        float kc = (field == 1) ? kn.x : kn.y;
+
+        v[s].x = h[s].y * kc;
+        v[s].y = -h[s].x * kc;
+      }
+
+      fft_line<N>(v, t, line, midtab, w, true);
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+        spec[field * plane + blocked<N>(y, t + T * s)] = v[s];
+    }
+
+    fft_line<N>(h, t, line, midtab, w, true);
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+      spec[blocked<N>(y, t + T * s)] = h[s];
+  }
+
+  //|---------------------- column pass + map ---------------------------------
+
+  template<int N>
+  struct ColCfg
+  {
+    static constexpr int T = Plan<N>::T;
+    static constexpr int W = (T * 8 <= 1024) ? 8 : 1024 / T;         // tile width in columns
+    static constexpr int THREADS = W * T;
+    static constexpr int MINWAVES = 4;
+    static constexpr int CS = Plan<N>::LINE + 2;                      // LDS column stride (complex), == 2 mod 16
+    static constexpr int SY = N + 4;                                  // height exchange: column stride (floats)
+
+    // LDS carve, in bytes: middle-pass twiddles | heights of the two halo columns | transform lines,
+    // later reused for the heights of the tile's own columns
+    static constexpr size_t OFF_HALO = (size_t)LineFFT<N>::MIDTAB * sizeof(cf);
+    static constexpr size_t OFF_MAIN = OFF_HALO + (size_t)2 * SY * sizeof(float);
+    static constexpr size_t MAIN_FFT = (size_t)W * CS * sizeof(cf);
+    static constexpr size_t MAIN_DZ = (size_t)W * SY * sizeof(float);
+    static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
+
+    static_assert(W >= 2 && T >= 2, "halo round needs two column slots");
+    static_assert(OFF_MAIN % 16 == 0, "LDS carve must stay 16-byte aligned");
+  };
+
+  template<int N>
+  __global__ void __launch_bounds__(ColCfg<N>::THREADS, ColCfg<N>::MINWAVES) ocean_colpass_kernel(StepArgs a)
+  {
+    typedef Plan<N> P;
+    typedef LineFFT<N> L;
+    typedef ColCfg<N> C;
+
+    constexpr int E = P::E;
+    constexpr int T = P::T;
+    constexpr int W = C::W;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    cf *midtab = reinterpret_cast<cf*>(smem);
+    float *dzhalo = reinterpret_cast<float*>(smem + C::OFF_HALO);     // [2][SY]: columns x0 - 1 and x0 + W
+    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [W][CS]
+    float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [W][SY], after the transforms
+
+    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
+      midtab[i] = L::midtab_entry(a.tw, i);
+
+    int const cascade = blockIdx.y;
+    int const x0 = blockIdx.x * W;
+
+    CascadeConst const cc = a.casc[cascade];
+
+    size_t const plane = (size_t)N * N;
+
+    cf const *spec = a.spec + cascade * 3 * plane;
+    float4 *layer0 = a.maps + (size_t)cascade * 2 * plane;
+    float4 *layer1 = layer0 + plane;
+
+    cf v[E];
+
+    // halo round first (nothing else is live yet): height of the two columns bordering the tile
+    // (periodic, map.comp:58).  Column slot hc = thread / T, row group ht = thread % T.
+    {
+      int const hc = threadIdx.x / T;
+      int const ht = threadIdx.x % T;
+
+      bool const halo = hc < 2;
+      int const hx = (hc == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
+      float const hsigma = ((hx + ht) & 1) ? -1.0f : 1.0f;
+
+      typename L::Twiddles hw;
+      L::load_twiddles(a.tw, ht, hw);
+
+      if (halo)
+      {
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+          v[s] = spec[blocked<N>(ht + T * s, hx)];
+      }
+
+      fft_line<N>(v, ht, lines + hc * C::CS, midtab, hw, halo);
+
+      if (halo)
+      {
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+          dzhalo[hc * C::SY + ht + T * s] = v[s].x * hsigma;
+      }
+    }
+
+    // main rounds: column c (fastest over lanes), row group t
+    int const c = threadIdx.x % W;
+    int const t = threadIdx.x / W;
+    int const x = x0 + c;
+
+    typename L::Twiddles w;
+    L::load_twiddles(a.tw, t, w);
+
+    // (-1)^(x+y) of map.comp:60; y = t + T s and T is even, so the sign is fixed per thread
+    float const sigma = ((x + t) & 1) ? -1.0f : 1.0f;
+
+    float dx[E], dy[E], dz[E];
+
+    // height, then choppy x / y displacement: Re(column transform) * sigma [* choppiness] (map.comp:62-64)
+    #pragma unroll
+    for(int field = 0; field < 3; ++field)
+    {
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+        v[s] = spec[field * plane + blocked<N>(t + T * s, x)];
+
+      fft_line<N>(v, t, lines + c * C::CS, midtab, w, true);
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+        if (field == 0) dz[s] = v[s].x * sigma;
+        if (field == 1) dx[s] = v[s].x * sigma * cc.choppiness;
+        if (field == 2) dy[s] = v[s].x * sigma * cc.choppiness;
+      }
+    }
+
+    // exchange heights (the transform lines are free after the last barrier of fft_line)
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+      dzmain[c * C::SY + t + T * s] = dz[s];
+
+    __syncthreads();
+
+    float const *left = (c == 0) ? dzhalo : dzmain + (c - 1) * C::SY;
+    float const *right = (c == W - 1) ? dzhalo + C::SY : dzmain + (c + 1) * C::SY;
+    float const *own = dzmain + c * C::SY;
+
+    // central-difference normal (map.comp:72-77) and the two image stores (map.comp:79-80)
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+    {
+      int y = t + T * s;
+
+      float nx = left[y] - right[y];
+      float ny = own[(y + 1) & (N - 1)] - own[(y + N - 1) & (N - 1)];
+      float nz = cc.nz;
+
+      float inv = rsqrtf(nx * nx + ny * ny + nz * nz);
+
+      layer0[(size_t)y * N + x] = make_float4(dx[s], dy[s], dz[s], 0.0f);
+      layer1[(size_t)y * N + x] = make_float4(nx * inv, ny * inv, nz * inv, 0.0f);
+    }
+  }
+
+  //|---------------------- phase-only advance --------------------------------
+  // used when more than MAX_PENDING updates are queued between two displace calls
+
+  __global__ void ocean_advance_kernel(StepArgs a, int N)
+  {
+    int const cascade = blockIdx.y;
+    size_t const plane = (size_t)N * N;
+
+    float *phase = a.phase + cascade * plane;
+    float const wavescale = a.casc[cascade].wavescale;
+
+    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x)
+    {
+      int m = (int)(i / N), n = (int)(i % N);
+
+      float omega = dispersion_at(n, m, N, wavescale);
+
+      float p = phase[i];
+      for(int k = 0; k < a.ndt; ++k)
+        p = advance_phase(p, omega * a.dt[k]);
+
+      phase[i] = p;
+    }
+  }
+
+  //|---------------------- diagnostics ---------------------------------------
+
+  // ocean.sim alone, row-major output (datum_ocean_debug_sim)
+  __global__ void ocean_sim_kernel(StepArgs a, int N, int cascade, cf *h, cf *hx, cf *hy)
+  {
+    size_t const plane = (size_t)N * N;
+
+    float2 const *h0 = a.h0 + cascade * plane;
+    float const *phase = a.phase + cascade * plane;
+    float const scale = a.casc[cascade].scale;
+
+    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x)
+    {
+      int y = (int)(i / N), x = (int)(i % N);
+
+      cf hh = sim_height(h0[i], h0[(size_t)(N - 1 - y) * N + (N - 1 - x)], phase[i]);
+      float2 kn = knorm_of(wavevector(x, N, scale), wavevector(y, N, scale));
+
+      h[i] = hh;
+      hx[i] = cf{ hh.y * kn.x, -hh.x * kn.x };
+      hy[i] = cf{ hh.y * kn.y, -hh.x * kn.y };
+    }
+  }
+
+  // blocked work spectrum -> row-major (datum_ocean_debug_rowpass)
+  __global__ void ocean_unblock_kernel(cf const *spec, int N, cf *out)
+  {
+    size_t const plane = (size_t)N * N;
+
+    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x)
+    {
+      int y = (int)(i / N), x = (int)(i % N);
+
+      out[i] = spec[((size_t)((y >> 3) * (N / 8) + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7)];
+    }
+  }
+
+  //|---------------------- ocean.gen -----------------------------------------
+
+  struct GenArgs
+  {
+    datum_ocean_set set;
+    float4 const *layer0;
+    float4 const *layer1;
+    int N;
+    int sizex;
+    int sizey;
+    float *vertices;
+  };
+
+  struct f3 { float x, y, z; };
+
+  __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+  __device__ __forceinline__ f3 operator*(float s, f3 a) { return { s * a.x, s * a.y, s * a.z }; }
+  __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+  __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+  __device__ __forceinline__ f3 normalize3(f3 a) { float l = sqrtf(dot3(a, a)); return { a.x / l, a.y / l, a.z / l }; }
+
+  // rotate v by the unit quaternion q = (w, x, y, z)   (data/transform.inc:32-37)
+  __device__ __forceinline__ f3 rotate(float const (&q)[4], f3 v)
+  {
+    f3 u = { q[1], q[2], q[3] };
+    f3 tt = 2.0f * cross3(u, v);
+
+    return v + q[0] * tt + cross3(u, tt);
+  }
+
+  // texture(sampler2DArray, REPEAT, linear, lod 0) at normalised (u, v): texel centres at (i + 0.5) / N
+  __device__ __forceinline__ f3 sample_repeat(float4 const *layer, int N, float u, float v)
+  {
+    float fx = u * (float)N - 0.5f;
+    float fy = v * (float)N - 0.5f;
+
+    float flx = floorf(fx);
+    float fly = floorf(fy);
+
+    float ax = fx - flx;
+    float ay = fy - fly;
+
+    long long ix = (long long)flx, iy = (long long)fly;
+
+    int i0 = (int)(((ix % N) + N) % N);
+    int j0 = (int)(((iy % N) + N) % N);
+    int i1 = (i0 + 1) & (N - 1);
+    int j1 = (j0 + 1) & (N - 1);
+
+    float4 t00 = layer[(size_t)j0 * N + i0];
+    float4 t10 = layer[(size_t)j0 * N + i1];
+    float4 t01 = layer[(size_t)j1 * N + i0];
+    float4 t11 = layer[(size_t)j1 * N + i1];
+
+    float w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
+
+    return { w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x,
+             w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+             w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z };
+  }
+
+  // data/ocean.gen.comp:67-137, one thread per mesh vertex
+  __global__ void __launch_bounds__(256) ocean_gen_kernel(GenArgs g)
+  {
+    int const xx = blockIdx.x * 16 + (threadIdx.x & 15);
+    int const yy = blockIdx.y * 16 + (threadIdx.x >> 4);
+
+    if (xx >= g.sizex || yy >= g.sizey)
+      return;
+
+    datum_ocean_set const &p = g.set;
+
+    size_t const index = (size_t)yy * g.sizex + xx;
+
+    // camerapos = 2 * (dual * conjugate(real)).yzw   (gen.comp:75, transform.inc:13-28)
+    float rw = p.camera_real[0], ri = -p.camera_real[1], rj = -p.camera_real[2], rk = -p.camera_real[3];
+    float dw = p.camera_dual[0], di = p.camera_dual[1], dj = p.camera_dual[2], dk = p.camera_dual[3];
+
+    f3 camerapos = { 2 * (dw * ri + di * rw + dj * rk - dk * rj),
+                     2 * (dw * rj + dj * rw + dk * ri - di * rk),
+                     2 * (dw * rk + dk * rw + di * rj - dj * ri) };
+
+    f3 planen = { p.plane[0], p.plane[1], p.plane[2] };
+
+    float cameraheight = dot3(planen, camerapos) + p.plane[3];
+
+    float margin = 1 + sqrtf((2 * p.swellamplitude + 0.5f) / cameraheight);
+
+    float u = (2 * (float)xx / (float)(g.sizex - 1) - 1) * margin;
+    float v = (1 - 2 * (float)yy / (float)(g.sizey - 1)) * margin;
+
+    float const *ip = p.invproj;
+
+    f3 viewvec = { ip[0] * u + ip[1] * v + ip[2] * 0.0f + ip[3] * 1.0f,
+                   ip[4] * u + ip[5] * v + ip[6] * 0.0f + ip[7] * 1.0f,
+                   ip[8] * u + ip[9] * v + ip[10] * 0.0f + ip[11] * 1.0f };
+
+    f3 worlddir = rotate(p.camera_real, normalize3(viewvec));
+
+    float costheta = dot3(worlddir, f3{ -planen.x, -planen.y, -planen.z });
+
+    float dist = (costheta > 0) ? cameraheight / costheta : 1e6f;
+
+    f3 baseposition = { camerapos.x + dist * worlddir.x, camerapos.y + dist * worlddir.y, -p.plane[3] };
+
+    // Gerstner swell (gen.comp:93-109)
+    float amplitude = p.swellamplitude;
+    float frequency = 2 * 3.14159265358979323846f / p.swelllength;
+    float dirx = p.swelldirection[0], diry = p.swelldirection[1];
+    float qi = p.swellsteepness / (frequency * amplitude * 4 + 1e-6f);
+
+    float phi = frequency * amplitude;
+    float theta = frequency * (dirx * baseposition.x + diry * baseposition.y) + p.swellphase;
+
+    float st, ct;
+    sincosf(theta, &st, &ct);
+
+    f3 position = { baseposition.x + qi * amplitude * dirx * ct, baseposition.y + qi * amplitude * diry * ct, baseposition.z + amplitude * st };
+
+    f3 normal = { phi * dirx * ct / 6, phi * diry * ct / 6, qi * phi * st };
+    f3 tangent = { qi * phi * dirx * dirx * st, qi * phi * diry * dirx * st, phi * dirx * ct / 6 };
+
+    f3 tbn2 = normalize3(f3{ -normal.x, -normal.y, 1 - normal.z });
+    f3 tbn0 = normalize3(f3{ 1 - tangent.x, -tangent.y, tangent.z });
+    f3 tbn1 = cross3(tbn0, tbn2);
+
+    float tu = position.x * p.scale;
+    float tv = position.y * p.scale;
+
+    f3 displacement = sample_repeat(g.layer0, g.N, tu, tv);
+    f3 dn = sample_repeat(g.layer1, g.N, tu, tv);
+
+    float cl = dist * p.smoothing - 0.35f;
+    cl = fminf(fmaxf(cl, 0.0f), 1.0f);
+    float smoothing = powf(cl, 0.2f);
+
+    f3 tn = dn.x * tbn0 + dn.y * tbn1 + dn.z * tbn2;
+
+    tbn2 = normalize3((1 - smoothing) * tn + smoothing * planen);
+
+    float d0 = tbn2.x;
+    tbn0 = normalize3(f3{ 1 - d0 * tbn2.x, 0 - d0 * tbn2.y, 0 - d0 * tbn2.z });
+
+    // Mesh::Vertex { position3, texcoord2, normal3, tangent4 } = 48 bytes, three 16-byte stores
+    float4 *out = reinterpret_cast<float4*>(g.vertices + 12 * index);
+
+    out[0] = make_float4(position.x - displacement.x, position.y - displacement.y, position.z + displacement.z, 0.1f * position.x);
+    out[1] = make_float4(0.1f * position.y, tbn2.x, tbn2.y, tbn2.z);
+    out[2] = make_float4(tbn0.x, tbn0.y, tbn0.z, -1.0f);
+  }
+}

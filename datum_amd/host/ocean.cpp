@@ -1,0 +1,546 @@
+//
+// ocean.cpp -- host side of the ocean path over the HIP module (see ocean.h)
+//
+// What stays on the host is what the reference runs once or rarely on the host: Phillips-spectrum
+// seeding (src/renderer/ocean.cpp:82-168), the parameter blends (:172-213), the scalar part of
+// update_ocean (:221,:235), the OceanSet header (:731-747) and the mesh index buffer (:275-286).
+// Everything per-point per-frame is enqueued on the device through include/datum_ocean_hip.h.
+//
+
+#include "ocean.h"
+
+#include <atomic>
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <stdexcept>
+#include <string>
+
+using namespace std;
+using namespace lml;
+
+namespace
+{
+  atomic<uint64_t> g_stateids{1};
+
+  void check(datum_ocean_t hip, int rc, char const *what)
+  {
+    if (rc != DATUM_OCEAN_OK)
+      throw runtime_error(string(what) + ": " + datum_ocean_last_error(hip));
+  }
+
+  // Phillips spectrum P(k) for wind speed v along w, amplitude a (ocean.cpp:89-107):
+  // a * d * exp(-1/(k^2 L^2)) / k^6 * (k.w)^2 * exp(-k^2 l^2), L = v^2/g, l = L/1000,
+  // waves running against the wind damped by d = 0.2; no energy at k = 0.
+  float phillips(Vec2 const &k, float a, float v, Vec2 const &w)
+  {
+    if (k.x == 0 && k.y == 0)
+      return 0.0f;
+
+    float const against = 0.2f;
+    float const damping = 0.001f;
+
+    float kdotw = dot(k, w);
+    float d = (kdotw < 0) ? against : 1.0f;
+
+    float L = v * v / 9.81f;
+    float L2 = L * L;
+    float l2 = L2 * damping * damping;
+
+    float k2 = normsqr(k);
+
+    return a * d * exp(-1.0f / (k2 * L2)) / (k2*k2*k2) * (kdotw*kdotw) * exp(-k2 * l2);
+  }
+
+  // one complex Gaussian sample by the polar method, at most 8 rejections (ocean.cpp:109-123)
+  bool gauss_pair(mt19937 &entropy, float &re, float &im)
+  {
+    uniform_real_distribution<float> real11{-1.0f, 1.0f};
+
+    float x = 0, y = 0, w = 1;
+
+    for(int tries = 0; tries < 8 && !(0 < w && w < 1); ++tries)
+    {
+      x = real11(entropy);
+      y = real11(entropy);
+      w = x*x + y*y;
+    }
+
+    float s = sqrt((-2*log(w)) / w);
+
+    re = x * s;
+    im = y * s;
+
+    return (0 < w && w < 1);
+  }
+
+  // h0(k) = seed(k) * dk * sqrt(P(k) / 2), k = dk * (n - N/2, m - N/2), dk = 2 pi / wavescale
+  // (ocean.cpp:148-165; the same loop again at :194-211)
+  void rebuild_height(OceanParams &params)
+  {
+    int const size = params.resolution;
+
+    float dk = 2*pi<float>() / params.wavescale;
+
+    for(int m = 0; m < size; ++m)
+    {
+      float ky = dk * (m - 0.5f*size);
+
+      for(int n = 0; n < size; ++n)
+      {
+        float kx = dk * (n - 0.5f*size);
+
+        float h0 = dk * sqrt(phillips(Vec2(kx, ky), params.waveamplitude, params.windspeed, params.winddirection) / 2.0f);
+
+        size_t i = 2 * ((size_t)m * size + n);
+
+        params.height[i+0] = params.seed[i+0] * h0;
+        params.height[i+1] = params.seed[i+1] * h0;
+      }
+    }
+
+    params.heightid = g_stateids++;
+  }
+
+  void seed_with(OceanParams &params, mt19937 &entropy)
+  {
+    size_t const points = (size_t)params.resolution * params.resolution;
+
+    params.swellphase = 0.0f;
+    params.rejectedseeds = 0;
+
+    // row-major (m outer, n inner): the order fixes which draw lands on which wave vector (ocean.cpp:134-146)
+    for(size_t i = 0; i < points; ++i)
+    {
+      if (!gauss_pair(entropy, params.seed[2*i+0], params.seed[2*i+1]))
+      {
+        // The reference evaluates sqrt(-2 log(w) / w) on a rejected w here and seeds a NaN (probability
+        // 4.5e-6 per point: harmless odds at 64 x 64, near-certain from 512 x 512 up, and one NaN poisons
+        // the whole transform).  Such a point gets no energy instead; the generator is consumed identically.
+        params.seed[2*i+0] = 0.0f;
+        params.seed[2*i+1] = 0.0f;
+        params.rejectedseeds += 1;
+      }
+    }
+
+    fill(params.phase.begin(), params.phase.end(), 0.0f);
+
+    rebuild_height(params);
+
+    params.flow = Vec2(0);
+    params.pending.clear();
+    params.stateid = g_stateids++;
+  }
+
+  // make the device hold this params' state: h0 (and phase when the whole state was replaced)
+  void bind_state(OceanContext &context, OceanParams const &params)
+  {
+    assert(params.resolution == context.resolution);
+
+    check(context.hip, datum_ocean_set_cascade(context.hip, 0, params.wavescale, params.choppiness), "datum_ocean_set_cascade");
+
+    if (context.boundstate != params.stateid)
+    {
+      check(context.hip, datum_ocean_upload_state(context.hip, 0, params.height.data(), params.phase.data()), "datum_ocean_upload_state");
+
+      context.boundstate = params.stateid;
+      context.boundheight = params.heightid;
+    }
+    else if (context.boundheight != params.heightid)
+    {
+      // lerp_ocean_waves changed h0 only: keep the device phase, which is ahead of params.phase
+      vector<float> phase(params.phase.size());
+
+      check(context.hip, datum_ocean_read_state(context.hip, 0, phase.data()), "datum_ocean_read_state");
+      check(context.hip, datum_ocean_upload_state(context.hip, 0, params.height.data(), phase.data()), "datum_ocean_upload_state");
+
+      context.boundheight = params.heightid;
+    }
+
+    for(float dt : params.pending)
+      check(context.hip, datum_ocean_update(context.hip, dt), "datum_ocean_update");
+
+    params.pending.clear();
+  }
+}
+
+
+//|---------------------- Camera --------------------------------------------
+//|--------------------------------------------------------------------------
+
+///////////////////////// Camera::Constructor ///////////////////////////////
+Camera::Camera()
+{
+  // camera.cpp:20-31
+  m_fov = 60.0f*pi<float>()/180.0f;
+  m_aspect = 1.7777f;
+  m_znear = 0.1f;
+  m_zfar = 1000.0f;
+  m_position = Vec3(0);
+  m_rotation = Quaternion3(1, 0, 0, 0);
+}
+
+
+///////////////////////// Camera::set_projection ////////////////////////////
+void Camera::set_projection(float fov, float aspect, float znear, float zfar)
+{
+  m_fov = fov;
+  m_aspect = aspect;
+  m_znear = znear;
+  m_zfar = zfar;
+}
+
+
+///////////////////////// Camera::proj //////////////////////////////////////
+Matrix4f Camera::proj() const
+{
+  // y flipped, reverse z (camera.cpp:77-91)
+  Matrix4f proj = {};
+
+  float halftan = tan(m_fov/2);
+  float depth = m_zfar - m_znear;
+
+  proj(0, 0) = 1 / (m_aspect * halftan);
+  proj(1, 1) = -1 / halftan;
+  proj(2, 2) = m_zfar / depth - 1;
+  proj(2, 3) = m_zfar * m_znear / depth;
+  proj(3, 2) = -1;
+
+  return proj;
+}
+
+
+///////////////////////// Camera::lookat ////////////////////////////////////
+void Camera::lookat(Vec3 const &position, Vec3 const &target, Vec3 const &up)
+{
+  m_position = position;
+  m_rotation = Transform::lookat(position, target, up).rotation();
+}
+
+
+//|---------------------- Ocean ---------------------------------------------
+//|--------------------------------------------------------------------------
+
+///////////////////////// OceanParams::Constructor //////////////////////////
+OceanParams::OceanParams(int resolution)
+  : resolution(resolution),
+    seed((size_t)resolution * resolution * 2, 0.0f),
+    height((size_t)resolution * resolution * 2, 0.0f),
+    phase((size_t)resolution * resolution, 0.0f)
+{
+}
+
+
+///////////////////////// OceanContext::Destructor //////////////////////////
+OceanContext::~OceanContext()
+{
+  if (hip)
+    datum_ocean_destroy(hip);
+}
+
+
+///////////////////////// seed_ocean ////////////////////////////////////////
+void seed_ocean(OceanParams &params)
+{
+  mt19937 entropy(random_device{}());
+
+  seed_with(params, entropy);
+}
+
+void seed_ocean(OceanParams &params, uint32_t rngseed)
+{
+  mt19937 entropy(rngseed);
+
+  seed_with(params, entropy);
+}
+
+
+///////////////////////// lerp_ocean_swell /////////////////////////////////
+void lerp_ocean_swell(OceanParams &params, float swelllength, float swellamplitude, float swellspeed, Vec2 swelldirection, float t)
+{
+  bool same = (params.swelllength == swelllength && params.swellamplitude == swellamplitude && params.swellspeed == swellspeed && params.swelldirection == swelldirection);
+
+  if (same)
+    return;
+
+  params.swelllength = lerp(params.swelllength, swelllength, t);
+  params.swellamplitude = lerp(params.swellamplitude, swellamplitude, t);
+  params.swellspeed = lerp(params.swellspeed, swellspeed, t);
+  params.swelldirection = normalise(lerp(params.swelldirection, swelldirection, t));
+}
+
+
+///////////////////////// lerp_ocean_waves //////////////////////////////////
+void lerp_ocean_waves(OceanParams &params, float wavescale, float waveamplitude, float windspeed, Vec2 winddirection, float t)
+{
+  bool same = (params.wavescale == wavescale && params.waveamplitude == waveamplitude && params.windspeed == windspeed && params.winddirection == winddirection);
+
+  if (same)
+    return;
+
+  params.wavescale = lerp(params.wavescale, wavescale, t);
+  params.waveamplitude = lerp(params.waveamplitude, waveamplitude, t);
+  params.windspeed = lerp(params.windspeed, windspeed, t);
+  params.winddirection = normalise(lerp(params.winddirection, winddirection, t));
+
+  // the spectrum envelope moved: new h0 from the stored seed (ocean.cpp:194-211)
+  rebuild_height(params);
+}
+
+
+///////////////////////// update_ocean ////////////////////////////////////
+void update_ocean(OceanParams &params, float dt)
+{
+  params.swellphase = fmod(params.swellphase + (params.swellspeed * 2*pi<float>()/params.swelllength)*dt, 2*pi<float>());
+
+  // phase[m][n] = fmod(phase[m][n] + dispersion(k)*dt, 2 pi) is done by the row-pass kernel, in queue order
+  params.pending.push_back(dt);
+
+  params.flow += params.windspeed * params.winddirection * dt;
+}
+
+
+///////////////////////// ResourceManager::create ///////////////////////////
+template<>
+Ocean const *ResourceManager::create<Ocean>(int sizex, int sizey)
+{
+  OceanContext &context = *m_context;
+
+  assert(context.hip);
+  assert(sizex >= 2 && sizey >= 2);
+
+  auto ocean = new Ocean;
+
+  ocean->context = &context;
+  ocean->sizex = sizex;
+  ocean->sizey = sizey;
+  ocean->state = Mesh::State::Empty;
+
+  size_t cells = (size_t)(sizex-1) * (sizey-1);
+
+  ocean->vertexbuffer.vertexcount = sizex * sizey;
+  ocean->vertexbuffer.vertexsize = sizeof(Mesh::Vertex);
+  ocean->vertexbuffer.indexcount = 6 * cells;
+  ocean->vertexbuffer.indexsize = sizeof(uint32_t);
+
+  if (datum_ocean_device_alloc(context.hip, (size_t)sizex * sizey * sizeof(Mesh::Vertex), &ocean->vertexbuffer.vertices) != DATUM_OCEAN_OK
+   || datum_ocean_device_alloc(context.hip, 6 * cells * sizeof(uint32_t), &ocean->vertexbuffer.indices) != DATUM_OCEAN_OK)
+  {
+    string why = datum_ocean_last_error(context.hip);
+    destroy<Ocean>(ocean);
+    throw runtime_error("HIP Create VertexBuffer failed: " + why);
+  }
+
+  // two triangles per grid cell; with a = (x, y), b = (x+1, y), c = (x, y+1), d = (x+1, y+1):
+  // (c, a, d) and (d, a, b) (ocean.cpp:275-286)
+  vector<uint32_t> indices;
+  indices.reserve(6 * cells);
+
+  for(int y = 0; y + 1 < sizey; ++y)
+  {
+    for(int x = 0; x + 1 < sizex; ++x)
+    {
+      uint32_t a = y * sizex + x;
+      uint32_t b = a + 1;
+      uint32_t c = a + sizex;
+      uint32_t d = c + 1;
+
+      indices.insert(indices.end(), { c, a, d, d, a, b });
+    }
+  }
+
+  check(context.hip, datum_ocean_device_write(context.hip, ocean->vertexbuffer.indices, indices.data(), indices.size() * sizeof(uint32_t)), "datum_ocean_device_write");
+
+  ocean->state = Mesh::State::Ready;
+
+  return ocean;
+}
+
+
+///////////////////////// ResourceManager::release //////////////////////////
+template<>
+void ResourceManager::release<Ocean>(Ocean const *ocean)
+{
+  // the reference defers the destroy until the frame that may still use it has retired
+  // (ocean.cpp:304-308); here the stream is drained by datum_ocean_device_free
+  destroy<Ocean>(ocean);
+}
+
+
+///////////////////////// ResourceManager::destroy //////////////////////////
+template<>
+void ResourceManager::destroy<Ocean>(Ocean const *ocean)
+{
+  if (ocean)
+  {
+    if (ocean->context && ocean->context->hip)
+    {
+      if (ocean->vertexbuffer.vertices)
+        datum_ocean_device_free(ocean->context->hip, ocean->vertexbuffer.vertices);
+
+      if (ocean->vertexbuffer.indices)
+        datum_ocean_device_free(ocean->context->hip, ocean->vertexbuffer.indices);
+    }
+
+    delete ocean;
+  }
+}
+
+
+///////////////////////// initialise_ocean_context //////////////////////////
+void initialise_ocean_context(DatumPlatform::PlatformInterface &platform, OceanContext &context, uint32_t queueindex)
+{
+  // the reference picks queue `queueindex` of the platform's render device (ocean.cpp:331-333) and creates
+  // its command buffer, fence and semaphore; here the HIP module owns one stream per handle, created in
+  // prepare_ocean_context, so only the device is recorded
+  (void)queueindex;
+
+  context.device = platform.hipdevice;
+}
+
+
+///////////////////////// prepare_ocean_context /////////////////////////////
+bool prepare_ocean_context(DatumPlatform::PlatformInterface &platform, OceanContext &context, AssetManager &assets)
+{
+  (void)platform;
+  (void)assets;
+
+  if (context.ready)
+    return true;
+
+  // pipelines, twiddles, work spectrum, displacement map (ocean.cpp:353-711) in one call; there are no
+  // streamed shader assets to wait for, so this never returns false -- it throws if the device refuses
+  int rc = datum_ocean_create(&context.hip, context.device, context.resolution, 1);
+
+  if (rc != DATUM_OCEAN_OK)
+    throw runtime_error(string("HIP ocean module create failed: ") + datum_ocean_last_error(nullptr));
+
+  context.ready = true;
+
+  return true;
+}
+
+
+///////////////////////// make_oceanset /////////////////////////////////////
+datum_ocean_set make_oceanset(Camera const &camera, OceanParams const &params)
+{
+  datum_ocean_set set = {};
+
+  Matrix4f proj = camera.proj();
+  Matrix4f invproj = inverse(proj);
+  Transform transform = camera.transform();
+
+  memcpy(set.proj, proj.m, sizeof(set.proj));
+  memcpy(set.invproj, invproj.m, sizeof(set.invproj));
+
+  float real[4] = { transform.real.w, transform.real.x, transform.real.y, transform.real.z };
+  float dual[4] = { transform.dual.w, transform.dual.x, transform.dual.y, transform.dual.z };
+
+  memcpy(set.camera_real, real, sizeof(real));
+  memcpy(set.camera_dual, dual, sizeof(dual));
+
+  set.plane[0] = params.plane.normal.x;
+  set.plane[1] = params.plane.normal.y;
+  set.plane[2] = params.plane.normal.z;
+  set.plane[3] = params.plane.distance;
+
+  set.swelllength = params.swelllength;
+  set.swellamplitude = params.swellamplitude;
+  set.swellsteepness = params.swellsteepness;
+  set.swellphase = params.swellphase;
+  set.swelldirection[0] = params.swelldirection.x;
+  set.swelldirection[1] = params.swelldirection.y;
+
+  set.scale = 1 / params.wavescale;
+  set.choppiness = params.choppiness;
+  set.smoothing = 1 / params.smoothing;
+
+  set.size = params.resolution;
+
+  return set;
+}
+
+
+///////////////////////// displace_ocean_surface ////////////////////////////
+void displace_ocean_surface(OceanContext &context, OceanParams const &params)
+{
+  assert(context.ready);
+
+  bind_state(context, params);
+
+  check(context.hip, datum_ocean_displace(context.hip), "datum_ocean_displace");
+}
+
+
+///////////////////////// render ////////////////////////////////////////////
+void render_ocean_surface(OceanContext &context, Ocean const *target, Camera const &camera, OceanParams const &params, void *const (&dependancies)[8])
+{
+  assert(context.ready);
+  assert(target->ready());
+
+  // no fence wait: work is ordered on the handle's stream and nothing on the host is overwritten
+  // (the reference waits because it rewrites the mapped oceanset, ocean.cpp:725-749)
+
+  for(void *dependancy : dependancies)
+  {
+    if (dependancy)
+      check(context.hip, datum_ocean_wait_event(context.hip, dependancy), "datum_ocean_wait_event");
+  }
+
+  datum_ocean_set set = make_oceanset(camera, params);
+
+  // sim -> fftx -> ffty -> map (ocean.cpp:769-789)
+  displace_ocean_surface(context, params);
+
+  // gen (ocean.cpp:791-793)
+  check(context.hip, datum_ocean_gen(context.hip, 0, &set, target->sizex, target->sizey, target->vertexbuffer.vertices), "datum_ocean_gen");
+
+  // submit signals rendercomplete (ocean.cpp:803)
+  check(context.hip, datum_ocean_signal(context.hip, &context.rendercomplete), "datum_ocean_signal");
+}
+
+
+///////////////////////// fetch_ocean_state /////////////////////////////////
+void fetch_ocean_state(OceanContext &context, OceanParams &params)
+{
+  assert(context.ready);
+
+  bind_state(context, params);
+
+  check(context.hip, datum_ocean_read_state(context.hip, 0, params.phase.data()), "datum_ocean_read_state");
+}
+
+
+///////////////////////// read_ocean_displacement ///////////////////////////
+void read_ocean_displacement(OceanContext &context, float *maps)
+{
+  assert(context.ready);
+
+  check(context.hip, datum_ocean_read_maps(context.hip, 0, maps), "datum_ocean_read_maps");
+}
+
+
+///////////////////////// read_ocean_vertices ///////////////////////////////
+void read_ocean_vertices(OceanContext &context, Ocean const *ocean, Mesh::Vertex *vertices)
+{
+  assert(context.ready);
+
+  check(context.hip, datum_ocean_device_read(context.hip, vertices, ocean->vertexbuffer.vertices, (size_t)ocean->sizex * ocean->sizey * sizeof(Mesh::Vertex)), "datum_ocean_device_read");
+}
+
+
+///////////////////////// ocean_twiddle_table ///////////////////////////////
+vector<float> ocean_twiddle_table(int resolution)
+{
+  int stages = 0;
+  while ((1 << stages) < resolution)
+    ++stages;
+
+  vector<float> weights((size_t)resolution * 2 * stages);
+
+  if (datum_ocean_reference_weights(resolution, weights.data()) != DATUM_OCEAN_OK)
+    throw runtime_error(string("ocean_twiddle_table: ") + datum_ocean_last_error(nullptr));
+
+  return weights;
+}

@@ -1,0 +1,235 @@
+//
+// ocean.h -- host-side mirror of datum's ocean API (src/renderer/ocean.h:12-99) over the HIP module
+//
+// Same type names, field names, defaults and free-function signatures as the reference, so code written
+// against datum's ocean API (examples/ocean/ocean.cpp:31,46-52,59,135,165,179) compiles against this header
+// with three documented differences:
+//   1. WaveResolution is a run-time value (OceanContext::resolution / OceanParams::resolution, default 64 =
+//      ocean.h:16); the [64][64] state arrays of OceanParams (ocean.h:69-71) are sized by it.
+//   2. The Vulkan objects of OceanContext are replaced by one opaque HIP-module handle
+//      (include/datum_ocean_hip.h); VkSemaphore dependencies become hipEvent_t handles (void*).
+//   3. update_ocean's phase loop (ocean.cpp:223-233) runs on the device: update_ocean() queues dt,
+//      render_ocean_surface() applies the queue in order, bit-identically.  OceanParams::phase on the host
+//      is the state as of the last fetch_ocean_state().
+// Device failures throw std::runtime_error as the reference does (ocean.cpp:271, vulkan.cpp:550);
+// misuse trips assert (ocean.cpp:351,722-723); prepare_ocean_context returns bool (ocean.cpp:493-501).
+//
+
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "lml.h"
+#include "../../include/datum_ocean_hip.h"
+
+//|---------------------- stand-ins for the surrounding engine ---------------
+// only what the ocean call sites name
+
+namespace DatumPlatform
+{
+  // src/platform.h: render_device() -> VkDevice + queues.  Here: which HIP device the ocean runs on.
+  struct PlatformInterface
+  {
+    int hipdevice = 0;
+  };
+}
+
+class AssetManager   // src/asset.h: the HIP module embeds its kernels, no asset pack is consulted
+{
+};
+
+class Camera   // src/renderer/camera.h:16-107, the subset the ocean path reads
+{
+  public:
+    Camera();
+
+    lml::Vec3 position() const { return m_position; }
+    lml::Quaternion3 rotation() const { return m_rotation; }
+
+    float fov() const { return m_fov; }
+    float aspect() const { return m_aspect; }
+    float znear() const { return m_znear; }
+    float zfar() const { return m_zfar; }
+
+    lml::Matrix4f proj() const;                                                                       // camera.cpp:77-91
+    lml::Transform transform() const { return lml::Transform::lookat(m_position, m_rotation); }       // camera.h:48
+
+    void set_projection(float fov, float aspect, float znear = 0.1f, float zfar = 24000.0f);          // camera.h:52
+    void set_position(lml::Vec3 const &position) { m_position = position; }
+    void set_rotation(lml::Quaternion3 const &rotation) { m_rotation = rotation; }
+    void lookat(lml::Vec3 const &position, lml::Vec3 const &target, lml::Vec3 const &up);             // camera.cpp:151-155
+
+  private:
+
+    float m_fov, m_aspect, m_znear, m_zfar;
+    lml::Vec3 m_position;
+    lml::Quaternion3 m_rotation;
+};
+
+class Mesh   // src/renderer/mesh.h:16-80, the parts Ocean uses
+{
+  public:
+
+    struct Vertex
+    {
+      lml::Vec3 position;
+      lml::Vec2 texcoord;
+      lml::Vec3 normal;
+      lml::Vec4 tangent;
+    };
+
+    enum class State { Empty, Loading, Waiting, Testing, Ready };
+
+    bool ready() const { return state == State::Ready; }
+
+    // vertex buffer in DEVICE memory (compute-writable, ocean.cpp:270) + static index buffer
+    struct VertexBuffer
+    {
+      uint32_t vertexcount = 0;
+      uint32_t vertexsize = 0;
+      uint32_t indexcount = 0;
+      uint32_t indexsize = 0;
+      void *vertices = nullptr;
+      void *indices = nullptr;
+    } vertexbuffer;
+
+    State state = State::Empty;
+};
+
+static_assert(sizeof(Mesh::Vertex) == 48, "Mesh::Vertex must be 48 bytes (mesh.h:20-26)");
+
+class Ocean;
+struct OceanContext;
+
+class ResourceManager   // src/renderer/resource.h: create / release / destroy for the Ocean mesh only
+{
+  public:
+    explicit ResourceManager(OceanContext &context) : m_context(&context) { }
+
+    template<typename Resource, typename ...Args>
+    Resource const *create(Args... args);
+
+    template<typename Resource>
+    void release(Resource const *resource);
+
+    template<typename Resource>
+    void destroy(Resource const *resource);
+
+  private:
+    OceanContext *m_context;
+};
+
+//|---------------------- Ocean ---------------------------------------------
+//|--------------------------------------------------------------------------
+
+struct OceanContext
+{
+  bool ready = false;
+
+  static const int WaveResolution = 64;   // ocean.h:16: the default; `resolution` is what is used
+
+  int resolution = WaveResolution;
+
+  int device = 0;
+
+  datum_ocean_t hip = nullptr;            // replaces vulkan / pipelines / oceanset / spectrum / displacementmap
+
+  void *rendercomplete = nullptr;         // hipEvent_t recorded behind the last render (ocean.h:45)
+
+  std::uint64_t boundstate = 0;           // which OceanParams state is resident on the device
+  std::uint64_t boundheight = 0;
+
+  OceanContext() = default;
+  OceanContext(OceanContext const &) = delete;
+  OceanContext &operator=(OceanContext const &) = delete;
+  ~OceanContext();
+};
+
+struct OceanParams
+{
+  lml::Plane plane = { { 0.0f, 0.0f, 1.0f }, 0.0f };
+
+  // Swell
+  float swelllength = 40.0f;
+  float swellamplitude = 0.8f;
+  float swellsteepness = 0.0f;
+  float swellspeed = 1.25f;
+  lml::Vec2 swelldirection = { 0.780869f, 0.624695f };
+
+  // Waves
+  float wavescale = 64.0f;
+  float waveamplitude = 0.00002f;
+  float windspeed = 30.0f;
+  lml::Vec2 winddirection = { 0.780869f, 0.624695f };
+  float choppiness = 1.35f;
+  float smoothing = 280.0f;
+
+  // State
+  float swellphase = 0.0f;
+  int resolution;                 // N (the reference: OceanContext::WaveResolution)
+  std::vector<float> seed;        // [N][N][2]
+  std::vector<float> height;      // [N][N][2]   h0
+  std::vector<float> phase;       // [N][N]      as of seed_ocean / the last fetch_ocean_state
+  lml::Vec2 flow = { 0.0f, 0.0f };
+
+  // device residency bookkeeping (not in the reference)
+  std::uint64_t stateid = 0;            // changes when seed_ocean replaces the whole state
+  std::uint64_t heightid = 0;           // changes when `height` is recomputed (lerp_ocean_waves)
+  mutable std::vector<float> pending;   // update_ocean dt's not yet applied on the device
+  int rejectedseeds = 0;                // seed pairs whose 8 polar draws were all rejected (see seed_ocean)
+
+  explicit OceanParams(int resolution = OceanContext::WaveResolution);
+};
+
+class Ocean : public Mesh
+{
+  public:
+    friend class ResourceManager;
+
+    int sizex;
+    int sizey;
+
+  protected:
+    Ocean() = default;
+
+    OceanContext *context = nullptr;
+};
+
+template<> Ocean const *ResourceManager::create<Ocean>(int sizex, int sizey);
+template<> void ResourceManager::release<Ocean>(Ocean const *ocean);
+template<> void ResourceManager::destroy<Ocean>(Ocean const *ocean);
+
+void seed_ocean(OceanParams &params);
+void seed_ocean(OceanParams &params, std::uint32_t rngseed);   // extension: reproducible entropy (the reference uses random_device, ocean.cpp:132)
+void lerp_ocean_swell(OceanParams &params, float swelllength, float swellamplitude, float swellspeed, lml::Vec2 swelldirection, float t);
+void lerp_ocean_waves(OceanParams &params, float wavescale, float waveamplitude, float windspeed, lml::Vec2 winddirection, float t);
+void update_ocean(OceanParams &params, float dt);
+
+// Initialise
+void initialise_ocean_context(DatumPlatform::PlatformInterface &platform, OceanContext &context, uint32_t queueindex);
+
+// Prepare
+bool prepare_ocean_context(DatumPlatform::PlatformInterface &platform, OceanContext &context, AssetManager &assets);
+
+// Render
+void render_ocean_surface(OceanContext &context, Ocean const *target, Camera const &camera, OceanParams const &params, void *const (&dependancies)[8] = {});
+
+// Extensions (not in the reference)
+
+// displacement maps only (ocean.sim .. ocean.map), no mesh: what the bench times
+void displace_ocean_surface(OceanContext &context, OceanParams const &params);
+
+// copy the device-resident phase back into params.phase (applies any queued update first)
+void fetch_ocean_state(OceanContext &context, OceanParams &params);
+
+// blocking read-backs for tools and tests
+void read_ocean_displacement(OceanContext &context, float *maps /* [2][N][N][4] */);
+void read_ocean_vertices(OceanContext &context, Ocean const *ocean, Mesh::Vertex *vertices);
+
+// the OceanSet header render_ocean_surface uploads (ocean.cpp:731-747)
+datum_ocean_set make_oceanset(Camera const &camera, OceanParams const &params);
+
+// the reference's twiddle table (ocean.cpp:686-700), N x 2 log2(N) floats; kept for API parity
+std::vector<float> ocean_twiddle_table(int resolution);

@@ -1,0 +1,162 @@
+/* datum_ocean_hip.h -- C ABI of the MI355X (gfx950) ocean compute module.
+ *
+ * This is the drop-in boundary: the entry points below replace what
+ * datum's src/renderer/ocean.cpp does through Vulkan compute between ":757" and ":803"
+ * (five bind_pipeline + dispatch pairs: ocean.sim, ocean.fftx, ocean.ffty, ocean.map,
+ * ocean.gen) plus the per-tick CPU phase advance of update_ocean (":217-236"), the
+ * twiddle/spectrum/displacement-map allocations of prepare_ocean_context (":686-711") and the
+ * per-frame OceanSet upload (":729-749").  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success; a negative DATUM_OCEAN_E* code for misuse; a positive
+ *     value is a hipError_t.  Nothing throws.  datum_ocean_last_error() gives the text.
+ *     (reference: throw std::runtime_error on device failure, ocean.cpp:271 / vulkan.cpp:550;
+ *     the C++ shim in datum_amd/host re-throws.)
+ *   - one HIP stream per handle; calls enqueue and return; datum_ocean_sync() is the fence wait of
+ *     ocean.cpp:725.  A handle is not re-entrant; distinct handles (GPUs) are independent.
+ *   - h0 / phase stay device resident (the reference re-uploads 12*N*N bytes per frame).
+ *   - "cascade" = one independent (OceanParams, N x N grid) problem; the reference has exactly one.
+ *   - all arrays are fp32, row-major [m = y][n = x] like OceanParams (ocean.h:69-71).
+ */
+
+#ifndef DATUM_OCEAN_HIP_H
+#define DATUM_OCEAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DATUM_OCEAN_MAX_CASCADES 16
+
+enum
+{
+  DATUM_OCEAN_OK = 0,
+  DATUM_OCEAN_EINVAL = -1,    /* bad argument (null pointer, unsupported resolution, cascade out of range) */
+  DATUM_OCEAN_ESTATE = -2,    /* call order misuse (e.g. displace before upload_state)                     */
+  DATUM_OCEAN_ENOMEM = -3
+};
+
+typedef struct datum_ocean_ctx *datum_ocean_t;
+
+/* The head of the reference's OceanSet SSBO (src/renderer/ocean.cpp:33-50; every shader mirrors it,
+ * e.g. data/ocean.gen.comp:15-36): std430, row_major, same byte offsets, sizeof == 216.
+ * Quaternions are (w, x, y, z) (data/transform.inc:13-28).  h0[] / phase[] that follow in the
+ * reference struct live on the device here (datum_ocean_upload_state). */
+typedef struct datum_ocean_set
+{
+  float proj[16];          /*   0  Camera::proj(), camera.cpp:77-89                        */
+  float invproj[16];       /*  64  inverse(proj), ocean.cpp:732                            */
+  float camera_real[4];    /* 128  camera.transform().real                                 */
+  float camera_dual[4];    /* 144  camera.transform().dual                                 */
+  float plane[4];          /* 160  (normal, distance), ocean.cpp:735                       */
+  float swelllength;       /* 176 */
+  float swellamplitude;    /* 180 */
+  float swellsteepness;    /* 184 */
+  float swellphase;        /* 188 */
+  float swelldirection[2]; /* 192 */
+  float scale;             /* 200  1 / wavescale, ocean.cpp:743                            */
+  float choppiness;        /* 204 */
+  float smoothing;         /* 208  1 / params.smoothing, ocean.cpp:745                     */
+  uint32_t size;           /* 212  WaveResolution                                          */
+} datum_ocean_set;
+
+/* -- lifetime (replaces initialise_ocean_context / prepare_ocean_context, ocean.cpp:325-716) ------------ */
+
+/* resolution: 64 (the reference's WaveResolution, ocean.h:16), 128, 256, 512, 1024, 2048 or 4096.
+ * Allocates h0, phase, the work spectrum (ocean.cpp:61-68) and the 2-layer RGBA32F displacement map
+ * (ocean.cpp:706) for `cascades` grids on HIP device `device`, and builds the twiddle table. */
+int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int cascades);
+int datum_ocean_destroy(datum_ocean_t ctx);
+
+/* Use the caller's hipStream_t (passed as void*) instead of the handle's own; NULL restores it. */
+int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream);
+
+/* Let the displacement maps be written into caller-owned DEVICE memory of
+ * cascades * 2 * N * N * 4 floats (e.g. a buffer that is later all-gathered); NULL restores the
+ * handle's own buffer. */
+int datum_ocean_bind_maps(datum_ocean_t ctx, void *device_ptr, size_t bytes);
+int datum_ocean_maps_device(datum_ocean_t ctx, void **device_ptr, size_t *bytes);
+
+/* -- state (OceanParams arrays, ocean.h:67-72) ------------------------------------------------------- */
+
+/* per-cascade wave constants used by sim / map: OceanSet.scale = 1/wavescale, OceanSet.choppiness */
+int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, float choppiness);
+
+/* h0 = OceanParams::height, N*N*2 floats (ocean.cpp:748); phase = OceanParams::phase, N*N floats
+ * (ocean.cpp:749) or NULL for all-zero (seed_ocean, ocean.cpp:144).  Host pointers. */
+int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, float const *phase);
+int datum_ocean_read_state(datum_ocean_t ctx, int cascade, float *phase);
+
+/* -- the per-frame path ---------------------------------------------------------------------------------- */
+
+/* update_ocean's phase advance (ocean.cpp:223-233) for every cascade:
+ * phase = fmod(phase + dispersion(k) * dt, 2 pi), in fp32, in call order.  It is applied on the device,
+ * fused into the next datum_ocean_displace (bit-identical to applying each dt in turn). */
+int datum_ocean_update(datum_ocean_t ctx, float dt);
+
+/* ocean.sim -> ocean.fftx -> ocean.ffty -> ocean.map for every cascade (ocean.cpp:769-789), as two fused
+ * kernels.  Result: per cascade [layer][y][x][4] floats, layer 0 = (dx, dy, dz, 0), layer 1 = (normal, 0)
+ * (data/ocean.map.comp:79-80). */
+int datum_ocean_displace(datum_ocean_t ctx);
+
+/* ocean.gen (data/ocean.gen.comp, ocean.cpp:791-793): fills sizex*sizey Mesh::Vertex (48 bytes:
+ * position3, texcoord2, normal3, tangent4 -- src/renderer/mesh.h:20-26) in DEVICE memory from the
+ * cascade's displacement map.  sizex, sizey: multiples of 16 in the reference; any size >= 2 here. */
+int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, int sizex, int sizey, void *vertices_device);
+
+/* blocking read-backs (host pointers).  maps: 2*N*N*4 floats. */
+int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps);
+
+/* wait_fence (ocean.cpp:725) */
+int datum_ocean_sync(datum_ocean_t ctx);
+
+/* Cross-queue ordering (the reference's VkSemaphores: up to 8 wait dependencies, vulkan.cpp:1308-1328, and the
+ * `rendercomplete` semaphore signalled by the submit, ocean.cpp:803, that render() waits on, renderer.cpp:6848).
+ * wait_event: work enqueued afterwards waits for the caller's hipEvent_t.  signal: records the handle's own
+ * completion hipEvent_t behind everything enqueued so far and returns it (owned by the handle). */
+int datum_ocean_wait_event(datum_ocean_t ctx, void *hip_event);
+int datum_ocean_signal(datum_ocean_t ctx, void **hip_event);
+
+/* Device memory for the Ocean mesh (vertex buffer with compute-writable usage + index buffer,
+ * ResourceManager::create<Ocean>, ocean.cpp:262-288) for hosts that do not link HIP themselves.
+ * write/read are ordered on the handle's stream; read blocks until the data is on the host. */
+int datum_ocean_device_alloc(datum_ocean_t ctx, size_t bytes, void **device_ptr);
+int datum_ocean_device_free(datum_ocean_t ctx, void *device_ptr);
+int datum_ocean_device_write(datum_ocean_t ctx, void *device_dst, void const *host_src, size_t bytes);
+int datum_ocean_device_read(datum_ocean_t ctx, void *host_dst, void const *device_src, size_t bytes);
+
+char const *datum_ocean_last_error(datum_ocean_t ctx);
+
+/* -- the reference's own host-side table, kept for API parity (ocean.cpp:686-700) ------------------------- */
+
+/* weights[i * 2*log2(N) + 2*s + {0,1}] = cos / sin(-2 pi i / 2^(s+1)) evaluated exactly as the reference
+ * does (fp32, unreduced angle).  The HIP kernels do not consume it. */
+int datum_ocean_reference_weights(int resolution, float *weights);
+
+/* -- diagnostics ------------------------------------------------------------------------------------------- */
+
+/* ocean.sim alone from the current device state (no phase advance): N*N*2 floats each, host pointers */
+int datum_ocean_debug_sim(datum_ocean_t ctx, int cascade, float *h, float *hx, float *hy);
+
+/* the work spectrum after the row pass of the last datum_ocean_displace (= state after ocean.fftx),
+ * converted back to row-major: N*N*2 floats each, host pointers */
+int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *h, float *hx, float *hy);
+
+/* hipEvent timing of the two kernels of datum_ocean_displace on the handle's stream.
+ * begin: start recording (at most max_steps displace calls); end: sync and return the mean kernel
+ * durations in milliseconds and the number of displace calls recorded. */
+int datum_ocean_profile_begin(datum_ocean_t ctx, int max_steps);
+int datum_ocean_profile_end(datum_ocean_t ctx, double *rowpass_ms, double *colpass_ms, int *steps);
+
+/* algorithmic bytes moved by one displace call of the handle (96 B per point per cascade;
+ * split: row pass 16 in + 24 out, column pass 24 in + 32 out) */
+int datum_ocean_algorithmic_bytes(datum_ocean_t ctx, double *rowpass_bytes, double *colpass_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,70 @@
+// CPU emulation of the thread-parallel line FFT in datum_amd/csrc/ocean_fft_core.h:
+// the T threads of a line are run one after another, phase by phase (a phase boundary is where
+// the kernels put a barrier), with an ordinary array standing in for the LDS line.
+// Test harness only: exercises the PRODUCT's index arithmetic and butterflies without a GPU.
+#include <cmath>
+#include <vector>
+#include "../../datum_amd/csrc/ocean_fft_core.h"
+
+using namespace ocean;
+
+template<int N>
+static void run_line(float const *in, float *out)
+{
+  typedef LineFFT<N> L;
+  typedef Plan<N> P;
+
+  std::vector<cf> tw(N);
+  for(int k = 0; k < N; ++k)
+  {
+    double a = 2.0 * M_PI * k / N;
+    tw[k] = cf{ (float)std::cos(a), (float)std::sin(a) };
+  }
+
+  std::vector<cf> line(P::LINE);
+  std::vector<cf> regs(N);   // [t][s]
+  std::vector<typename L::Twiddles> w(P::T);
+  std::vector<cf> midtab(L::MIDTAB + 1);
+  for(int i = 0; i < L::MIDTAB; ++i)
+    midtab[i] = L::midtab_entry(tw.data(), i);
+
+  for(int t = 0; t < P::T; ++t)
+  {
+    L::load_twiddles(tw.data(), t, w[t]);
+    for(int s = 0; s < P::E; ++s)
+      regs[t*P::E + s] = cf{ in[2*(t + P::T*s)], in[2*(t + P::T*s)+1] };
+  }
+
+  auto R = [&](int t) -> cf (&)[P::E] { return *reinterpret_cast<cf (*)[P::E]>(&regs[t*P::E]); };
+
+  for(int t = 0; t < P::T; ++t) L::pass0(R(t), t, line.data());
+  if (P::NP == 3)
+  {
+    for(int t = 0; t < P::T; ++t) L::mid_load(R(t), t, line.data(), midtab.data());
+    for(int t = 0; t < P::T; ++t) L::mid_store(R(t), t, line.data());
+  }
+  for(int t = 0; t < P::T; ++t) L::last(R(t), t, line.data(), w[t]);
+
+  for(int t = 0; t < P::T; ++t)
+    for(int s = 0; s < P::E; ++s)
+    {
+      out[2*(t + P::T*s)] = regs[t*P::E + s].x;
+      out[2*(t + P::T*s)+1] = regs[t*P::E + s].y;
+    }
+}
+
+extern "C" int emul_line_ifft(int N, float const *in, float *out)
+{
+  switch(N)
+  {
+    case 64: run_line<64>(in, out); break;
+    case 128: run_line<128>(in, out); break;
+    case 256: run_line<256>(in, out); break;
+    case 512: run_line<512>(in, out); break;
+    case 1024: run_line<1024>(in, out); break;
+    case 2048: run_line<2048>(in, out); break;
+    case 4096: run_line<4096>(in, out); break;
+    default: return -1;
+  }
+  return 0;
+}

@@ -1,0 +1,94 @@
+"""CPU tests: the oracle reproduces the committed golden fixtures, and the C-ABI library loads and exports
+every symbol include/datum_ocean_hip.h declares (no compute calls: there is no GPU here)."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "ocean_n64.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+def test_oracle_reproduces_golden(oracle, golden):
+    p = oracle.EXAMPLE
+    N = 64
+    seed, h0 = oracle.seed(N, 1000, p["wavescale"], p["waveamplitude"], p["windspeed"], p["winddirection"], sanitize=False)
+    assert np.array_equal(seed, golden["seed"])
+    assert np.array_equal(h0, golden["h0"])
+    phase = np.zeros((N, N), np.float32)
+    done = 0
+    for steps in (1, 60, 600):
+        for _ in range(steps - done):
+            oracle.update(phase, p["wavescale"], np.float32(1 / 60))
+        done = steps
+        assert np.array_equal(phase, golden[f"phase_{steps}"])
+        m = oracle.displace(h0, phase.copy(), p["wavescale"], p["choppiness"], dt=0.0)
+        assert np.array_equal(m, golden[f"maps_{steps}"])
+    s = oracle.example_oceanset(N, swellphase=0.25)
+    assert bytes(s) == golden["oceanset"].tobytes()
+    v = oracle.gen(s, golden["maps_600"], 32, 32)
+    assert np.allclose(v, golden["vertices_600_32x32"], rtol=0, atol=1e-6)
+
+
+def test_fused_update_equals_separate(oracle, golden):
+    # oracle.displace(dt) == update(dt) then displace(0): what the HIP row pass fuses
+    p = oracle.EXAMPLE
+    ph = golden["phase_60"].copy()
+    a = oracle.displace(golden["h0"], ph, p["wavescale"], p["choppiness"], dt=np.float32(1 / 60))
+    ph2 = golden["phase_60"].copy()
+    oracle.update(ph2, p["wavescale"], np.float32(1 / 60))
+    b = oracle.displace(golden["h0"], ph2.copy(), p["wavescale"], p["choppiness"], dt=0.0)
+    assert np.array_equal(ph, ph2)
+    assert np.array_equal(a, b)
+
+
+def test_abi_exports_every_declared_symbol():
+    from datum_amd import capi
+
+    header = open(os.path.join(ROOT, "include", "datum_ocean_hip.h")).read()
+    declared = set(re.findall(r"\b(datum_ocean_[a-z_]+)\s*\(", header))
+    declared -= {"datum_ocean_ctx"}
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    lib = capi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_abi_struct_layout():
+    from datum_amd import capi
+
+    S = capi.OceanSet
+    # byte offsets of src/renderer/ocean.cpp:33-50 under std430
+    want = dict(proj=0, invproj=64, camera_real=128, camera_dual=144, plane=160, swelllength=176, swellamplitude=180,
+                swellsteepness=184, swellphase=188, swelldirection=192, scale=200, choppiness=204, smoothing=208, size=212)
+    for k, off in want.items():
+        assert getattr(S, k).offset == off, k
+    assert ctypes.sizeof(S) == 216
+
+
+def test_abi_argument_errors_without_gpu():
+    from datum_amd import capi
+
+    lib = capi.load()
+    h = capi.P()
+    assert lib.datum_ocean_create(ctypes.byref(h), 0, 100, 1) == capi.EINVAL
+    assert b"resolution" in lib.datum_ocean_last_error(None)
+    assert lib.datum_ocean_create(ctypes.byref(h), 0, 64, 0) == capi.EINVAL
+    assert lib.datum_ocean_create(None, 0, 64, 1) == capi.EINVAL
+    assert lib.datum_ocean_displace(None) == capi.EINVAL
+    assert lib.datum_ocean_destroy(None) == capi.OK
+
+
+def test_reference_weights_match_oracle(oracle):
+    from datum_amd import capi
+
+    for N in (64, 256, 1024):
+        assert np.array_equal(capi.reference_weights(N), oracle.weights(N))
