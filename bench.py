@@ -112,7 +112,8 @@ def main():
     # maps land in a torch tensor so that RCCL can gather them in place; kernels run on torch's stream
     maps = torch.empty(C * 2 * N * N * 4, dtype=torch.float32, device=dev)
     oc.bind_maps(maps.data_ptr(), maps.numel() * 4)
-    stream = torch.cuda.current_stream(dev)
+    stream = torch.cuda.Stream(dev)   # a real (non-default) stream: events and RCCL below are ordered on it too
+    torch.cuda.set_stream(stream)
     oc.set_stream(stream.cuda_stream)
     gathered = torch.empty(world * maps.numel(), dtype=torch.float32, device=dev) if (world > 1 and args.gather == "batch") else None
 
@@ -218,7 +219,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     oc.bind_maps(0, 0)
-    oc.set_stream(0)
+    oc.set_stream(None)
     oc.close()
 
     if world > 1:

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(_HERE, "lib", "libdatum_ocean_hip.so")
+# DATUM_OCEAN_HIP_LIB selects another build of the same module (tuning variants); never a different implementation
+LIBPATH = os.environ.get("DATUM_OCEAN_HIP_LIB") or os.path.join(_HERE, "lib", "libdatum_ocean_hip.so")
 
 F = ctypes.c_float
 I = ctypes.c_int
@@ -49,7 +50,7 @@ assert ctypes.sizeof(OceanSet) == 216
 SYMBOLS = {
     "datum_ocean_create": (I, [ctypes.POINTER(P), I, I, I]),
     "datum_ocean_destroy": (I, [P]),
-    "datum_ocean_set_stream": (I, [P, P]),
+    "datum_ocean_set_stream": (I, [P, P, I]),
     "datum_ocean_bind_maps": (I, [P, P, ctypes.c_size_t]),
     "datum_ocean_maps_device": (I, [P, ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]),
     "datum_ocean_set_cascade": (I, [P, I, F, F]),
@@ -87,6 +88,14 @@ def load():
                 f"{LIBPATH} not found: build the HIP module first (`make` or __graft_entry__.build()); "
                 "datum_amd has no CPU fallback"
             )
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 + libhsa-runtime64 and the
+        # module links the same SONAME from /opt/rocm.  Whichever is mapped first serves both; torch cannot
+        # initialise on top of the system pair, so when torch is importable it goes first (it is also what the
+        # tests and bench.py use for device buffers and streams, which must come from the same runtime).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIBPATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
@@ -143,7 +152,11 @@ class Ocean:
         self.close()
 
     def set_stream(self, stream_ptr):
-        self._check(self.lib.datum_ocean_set_stream(self.h, P(stream_ptr) if stream_ptr else None))
+        """stream_ptr: a hipStream_t as an integer (0 = HIP's default stream); None = the handle's own stream."""
+        if stream_ptr is None:
+            self._check(self.lib.datum_ocean_set_stream(self.h, None, 1))
+        else:
+            self._check(self.lib.datum_ocean_set_stream(self.h, P(stream_ptr), 0))
 
     def bind_maps(self, device_ptr, nbytes):
         self._check(self.lib.datum_ocean_bind_maps(self.h, P(device_ptr) if device_ptr else None, nbytes))

@@ -64,6 +64,8 @@ namespace
 
     (ctx ? ctx->error : g_error) = buf;
 
+    (void)hipGetLastError();   // the runtime's sticky last-error must not leak into a later, unrelated call
+
     return code;
   }
 
@@ -104,19 +106,21 @@ namespace
   }
 
   template<int N>
-  void launch_rowpass(datum_ocean_ctx *ctx, StepArgs const &a)
+  hipError_t launch_rowpass(datum_ocean_ctx *ctx, StepArgs &a)
   {
     dim3 grid(N / RowCfg<N>::ROWS, ctx->cascades);
+    void *args[] = { &a };
 
-    hipLaunchKernelGGL(ocean_rowpass_kernel<N>, grid, dim3(RowCfg<N>::THREADS), RowCfg<N>::LDS, ctx->stream, a);
+    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), grid, dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream);
   }
 
   template<int N>
-  void launch_colpass(datum_ocean_ctx *ctx, StepArgs const &a)
+  hipError_t launch_colpass(datum_ocean_ctx *ctx, StepArgs &a)
   {
     dim3 grid(N / ColCfg<N>::W, ctx->cascades);
+    void *args[] = { &a };
 
-    hipLaunchKernelGGL(ocean_colpass_kernel<N>, grid, dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, ctx->stream, a);
+    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), grid, dim3(ColCfg<N>::THREADS), args, ColCfg<N>::LDS, ctx->stream);
   }
 
   #define DISPATCH_N(n, expr) \
@@ -271,7 +275,7 @@ int datum_ocean_destroy(datum_ocean_t ctx)
   return DATUM_OCEAN_OK;
 }
 
-int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream)
+int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream, int use_own)
 {
   if (!ctx)
     return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_set_stream: null handle");
@@ -279,7 +283,7 @@ int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream)
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
 
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->ownstream;
+  ctx->stream = use_own ? ctx->ownstream : (hipStream_t)hip_stream;
 
   return DATUM_OCEAN_OK;
 }
@@ -442,14 +446,16 @@ int datum_ocean_displace(datum_ocean_t ctx)
   if (prof)
     HIPCHECK(ctx, hipEventRecord(ev[0], ctx->stream));
 
-  DISPATCH_N(ctx->N, launch_rowpass<NN>(ctx, a));
-  HIPCHECK(ctx, hipGetLastError());
+  hipError_t le = hipSuccess;
+
+  DISPATCH_N(ctx->N, le = launch_rowpass<NN>(ctx, a));
+  HIPCHECK(ctx, le);
 
   if (prof)
     HIPCHECK(ctx, hipEventRecord(ev[1], ctx->stream));
 
-  DISPATCH_N(ctx->N, launch_colpass<NN>(ctx, a));
-  HIPCHECK(ctx, hipGetLastError());
+  DISPATCH_N(ctx->N, le = launch_colpass<NN>(ctx, a));
+  HIPCHECK(ctx, le);
 
   if (prof)
   {

@@ -46,21 +46,27 @@ namespace ocean
 
   constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
 
-  // N = E^(NP-1) * RL: NP-1 passes of radix E, one last pass of radix RL <= E done as M = E/RL tasks
+  // N = E^(NP-1) * RL: NP-1 passes of radix E, one last pass of radix RL <= E done as M = E/RL tasks.
+  // E = 8 keeps a line transform near 50 VGPRs (E = 16: ~90), which is what lets two 1024-thread
+  // workgroups share a CU without spilling; 4096 uses E = 16 to stay within 1024 threads per tile.
+  constexpr int plan_passes(int n, int e) { return n <= e ? 1 : 1 + plan_passes(n / e, e); }
+
   template<int N>
   struct Plan
   {
     static_assert(N == 64 || N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096, "unsupported resolution");
 
-    static constexpr int E = (N == 64) ? 4 : (N == 128 || N == 512) ? 8 : 16;
+    static constexpr int E = (N == 64) ? 4 : (N == 4096) ? 16 : 8;
     static constexpr int T = N / E;
-    static constexpr int NP = (N == 256) ? 2 : 3;
+    static constexpr int NP = plan_passes(N, E);
     static constexpr int RL = N / ipow(E, NP - 1);
     static constexpr int M = E / RL;
     static constexpr int NS_LAST = N / RL;      // product of the radices before the last pass
     static constexpr int LINE = N + N / 16;     // padded LDS line length, in complex elements
 
+    static_assert(NP >= 2 && NP <= 4, "bad plan");
     static_assert(RL >= 2 && RL <= E && E % RL == 0, "bad plan");
+    static_assert(ipow(E, NP - 1) * RL == N, "bad plan");
   };
 
   // LDS index padding: one extra element every 16, breaks the power-of-two strides of the pass-0 stores
@@ -211,23 +217,34 @@ namespace ocean
     static constexpr int RL = P::RL;
     static constexpr int M = P::M;
 
-    // per-thread twiddles kept in registers: the last pass (Ns = N / RL) needs w1 = exp(2 pi i j / N)
-    // for its tasks j = t + T m; higher powers come from twiddle_powers
+    // per-thread twiddles kept in registers, each the first power of its pass; higher powers come from
+    // twiddle_powers.  last[m] = exp(2 pi i j / N) for the last pass's tasks j = t + T m (Ns = N / RL);
+    // mid[k] = exp(2 pi i (t % Ns) / (Ns E)) for middle pass k + 2 (Ns = E^(k+2)).
+    static constexpr int NMIDREG = (P::NP > 3) ? P::NP - 3 : 1;
+
     struct Twiddles
     {
+      cf mid[NMIDREG];
       cf last[M];
     };
 
     static OC_HD void load_twiddles(cf const *tw, int t, Twiddles &w)
     {
       OC_UNROLL
+      for(int k = 0; k < NMIDREG; ++k)
+      {
+        int ns = ipow(E, k + 2);
+        w.mid[k] = (P::NP > 3) ? tw[((t % ns) * (N / (ns * E))) % N] : cf{ 1.0f, 0.0f };
+      }
+
+      OC_UNROLL
       for(int m = 0; m < M; ++m)
         w.last[m] = tw[((t + T * m) % P::NS_LAST) * (N / (P::NS_LAST * RL))];
     }
 
-    // middle pass (Ns = E) twiddles, shared by every line: midtab[r E + a] = exp(2 pi i a r / E^2),
-    // a = t % E fastest so that a wave reads 16 consecutive entries per r.  E*E entries (in LDS).
-    static constexpr int MIDTAB = (P::NP == 3) ? E * E : 0;
+    // first middle pass (Ns = E) twiddles, shared by every line: midtab[r E + a] = exp(2 pi i a r / E^2),
+    // a = t % E fastest so that a wave reads consecutive entries per r.  E*E entries (in LDS).
+    static constexpr int MIDTAB = (P::NP >= 3) ? E * E : 0;
 
     static OC_HD cf midtab_entry(cf const *tw, int i)
     {
@@ -246,27 +263,43 @@ namespace ocean
         line[padidx(t * E + q)] = v[q];
     }
 
-    // middle pass (NP == 3): Ns = E, radix E, task j = t.  load + twiddle + butterfly
-    static OC_HD void mid_load(cf (&v)[E], int t, cf const *line, cf const *midtab)
+    // middle pass PASS (1 <= PASS <= NP-2): Ns = E^PASS, radix E, task j = t.  load + twiddle + butterfly
+    template<int PASS>
+    static OC_HD void mid_load(cf (&v)[E], int t, cf const *line, cf const *midtab, Twiddles const &w)
     {
       OC_UNROLL
       for(int r = 0; r < E; ++r)
         v[r] = line[padidx(t + T * r)];
 
-      OC_UNROLL
-      for(int r = 1; r < E; ++r)
-        v[r] = cmul(v[r], midtab[r * E + (t % E)]);
+      if (PASS == 1)
+      {
+        OC_UNROLL
+        for(int r = 1; r < E; ++r)
+          v[r] = cmul(v[r], midtab[r * E + (t % E)]);
+      }
+      else
+      {
+        cf p[E];
+        twiddle_powers<E>(w.mid[PASS >= 2 ? PASS - 2 : 0], p);
+
+        OC_UNROLL
+        for(int r = 1; r < E; ++r)
+          v[r] = cmul(v[r], p[r]);
+      }
 
       Radix<E>::run(v);
     }
 
+    template<int PASS>
     static OC_HD void mid_store(cf const (&v)[E], int t, cf *line)
     {
-      int base = (t / E) * E * E + (t % E);
+      constexpr int Ns = ipow(E, PASS);
+
+      int base = (t / Ns) * Ns * E + (t % Ns);
 
       OC_UNROLL
       for(int q = 0; q < E; ++q)
-        line[padidx(base + q * E)] = v[q];
+        line[padidx(base + q * Ns)] = v[q];
     }
 
     // last pass: Ns = N/RL, radix RL, tasks j = t + T m.  result slot m + q M holds X[t + T (m + q M)]

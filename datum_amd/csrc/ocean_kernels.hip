@@ -4,10 +4,11 @@
 // :769-793) is done here in two fused kernels (+ gen):
 //
 //   row pass    update_ocean phase advance (ocean.cpp:223-233) + ocean.sim (data/ocean.sim.comp:44-79)
-//               + ocean.fftx (data/ocean.fftx.comp:49-100), one wave64-sized thread group per row
+//               + ocean.fftx (data/ocean.fftx.comp:49-100), N/8 threads per row, a few rows per workgroup
 //               reads  h0 (8 B/pt, plus its mirror row through L2), phase (4)   writes phase (4), spectrum (24)
 //   column pass ocean.ffty (data/ocean.ffty.comp:49-100) + ocean.map (data/ocean.map.comp:51-82),
-//               one workgroup per 8-column tile          reads spectrum (24)    writes 2 x RGBA32F (32)
+//               one workgroup per tile of W columns, two adjacent columns per thread (16-byte loads / stores)
+//               reads spectrum (24)    writes 2 x RGBA32F (32)
 //
 // = 96 algorithmic bytes per grid point against the reference's 196.
 //
@@ -124,15 +125,28 @@ namespace ocean
 
     __syncthreads();
 
-    if (Plan<N>::NP == 3)
+    if (Plan<N>::NP >= 3)
     {
       if (active)
-        L::mid_load(v, t, line, midtab);
+        L::template mid_load<1>(v, t, line, midtab, w);
 
       __syncthreads();
 
       if (active)
-        L::mid_store(v, t, line);
+        L::template mid_store<1>(v, t, line);
+
+      __syncthreads();
+    }
+
+    if (Plan<N>::NP >= 4)
+    {
+      if (active)
+        L::template mid_load<2>(v, t, line, midtab, w);
+
+      __syncthreads();
+
+      if (active)
+        L::template mid_store<2>(v, t, line);
 
       __syncthreads();
     }
@@ -145,13 +159,26 @@ namespace ocean
 
   //|---------------------- row pass ------------------------------------------
 
+#ifndef OCEAN_ROW_THREADS
+#define OCEAN_ROW_THREADS 512
+#endif
+#ifndef OCEAN_ROW_MINWAVES
+#define OCEAN_ROW_MINWAVES 6
+#endif
+#ifndef OCEAN_COL_THREADS
+#define OCEAN_COL_THREADS 512
+#endif
+#ifndef OCEAN_COL_MINWAVES
+#define OCEAN_COL_MINWAVES 4
+#endif
+
   template<int N>
   struct RowCfg
   {
     static constexpr int T = Plan<N>::T;
-    static constexpr int ROWS = (512 / T) < 8 ? (512 / T) : 8;
+    static constexpr int ROWS = (OCEAN_ROW_THREADS / T) < 1 ? 1 : (OCEAN_ROW_THREADS / T) > 8 ? 8 : (OCEAN_ROW_THREADS / T);
     static constexpr int THREADS = ROWS * T;
-    static constexpr int MINWAVES = 4;                                  // per SIMD: two 512-thread workgroups per CU
+    static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_ROW_MINWAVES : 4;        // per SIMD
     static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)ROWS * Plan<N>::LINE) * sizeof(cf);
   };
 
@@ -276,21 +303,22 @@ namespace ocean
   struct ColCfg
   {
     static constexpr int T = Plan<N>::T;
-    static constexpr int W = (T * 8 <= 1024) ? 8 : 1024 / T;         // tile width in columns
-    static constexpr int THREADS = W * T;
-    static constexpr int MINWAVES = 4;
-    static constexpr int CS = Plan<N>::LINE + 2;                      // LDS column stride (complex), == 2 mod 16
-    static constexpr int SY = N + 4;                                  // height exchange: column stride (floats)
+    static constexpr int WC = (OCEAN_COL_THREADS / T) < 1 ? 1 : (OCEAN_COL_THREADS / T) > 8 ? 8 : (OCEAN_COL_THREADS / T);   // columns in flight
+    static constexpr int W = 2 * WC;                                    // tile width: two adjacent columns per thread
+    static constexpr int THREADS = WC * T;
+    static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_COL_MINWAVES : 4;
+    static constexpr int CS = Plan<N>::LINE + 2;                        // LDS column stride (complex), == 2 mod 16
+    static constexpr int SY = N + 4;                                    // height exchange: column stride (floats)
 
-    // LDS carve, in bytes: middle-pass twiddles | heights of the two halo columns | transform lines,
+    // LDS carve, in bytes: first middle-pass twiddles | heights of the two halo columns | transform lines,
     // later reused for the heights of the tile's own columns
     static constexpr size_t OFF_HALO = (size_t)LineFFT<N>::MIDTAB * sizeof(cf);
     static constexpr size_t OFF_MAIN = OFF_HALO + (size_t)2 * SY * sizeof(float);
-    static constexpr size_t MAIN_FFT = (size_t)W * CS * sizeof(cf);
+    static constexpr size_t MAIN_FFT = (size_t)WC * CS * sizeof(cf);
     static constexpr size_t MAIN_DZ = (size_t)W * SY * sizeof(float);
     static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
 
-    static_assert(W >= 2 && T >= 2, "halo round needs two column slots");
+    static_assert(N % W == 0 && W % 2 == 0, "bad tile width");
     static_assert(OFF_MAIN % 16 == 0, "LDS carve must stay 16-byte aligned");
   };
 
@@ -304,12 +332,13 @@ namespace ocean
     constexpr int E = P::E;
     constexpr int T = P::T;
     constexpr int W = C::W;
+    constexpr int WC = C::WC;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     cf *midtab = reinterpret_cast<cf*>(smem);
     float *dzhalo = reinterpret_cast<float*>(smem + C::OFF_HALO);     // [2][SY]: columns x0 - 1 and x0 + W
-    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [W][CS]
+    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [WC][CS]
     float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [W][SY], after the transforms
 
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
@@ -326,95 +355,124 @@ namespace ocean
     float4 *layer0 = a.maps + (size_t)cascade * 2 * plane;
     float4 *layer1 = layer0 + plane;
 
-    cf v[E];
-
-    // halo round first (nothing else is live yet): height of the two columns bordering the tile
+    // halo rounds first (nothing else is live yet): height of the two columns bordering the tile
     // (periodic, map.comp:58).  Column slot hc = thread / T, row group ht = thread % T.
     {
       int const hc = threadIdx.x / T;
       int const ht = threadIdx.x % T;
 
-      bool const halo = hc < 2;
-      int const hx = (hc == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
-      float const hsigma = ((hx + ht) & 1) ? -1.0f : 1.0f;
-
       typename L::Twiddles hw;
       L::load_twiddles(a.tw, ht, hw);
 
-      if (halo)
+      #pragma unroll
+      for(int first = 0; first < 2; first += WC)
       {
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-          v[s] = spec[blocked<N>(ht + T * s, hx)];
-      }
+        int const side = first + hc;
+        bool const halo = side < 2;
+        int const hx = (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
+        float const hsigma = ((hx + ht) & 1) ? -1.0f : 1.0f;
 
-      fft_line<N>(v, ht, lines + hc * C::CS, midtab, hw, halo);
+        cf v[E];
 
-      if (halo)
-      {
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-          dzhalo[hc * C::SY + ht + T * s] = v[s].x * hsigma;
+        if (halo)
+        {
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+            v[s] = spec[blocked<N>(ht + T * s, hx)];
+        }
+
+        fft_line<N>(v, ht, lines + hc * C::CS, midtab, hw, halo);
+
+        if (halo)
+        {
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+            dzhalo[side * C::SY + ht + T * s] = v[s].x * hsigma;
+        }
       }
     }
 
-    // main rounds: column c (fastest over lanes), row group t
-    int const c = threadIdx.x % W;
-    int const t = threadIdx.x / W;
-    int const x = x0 + c;
+    // main rounds: column pair cp (fastest over lanes) = columns xa, xa + 1; row group t
+    int const cp = threadIdx.x % WC;
+    int const t = threadIdx.x / WC;
+    int const xa = x0 + 2 * cp;
 
     typename L::Twiddles w;
     L::load_twiddles(a.tw, t, w);
 
-    // (-1)^(x+y) of map.comp:60; y = t + T s and T is even, so the sign is fixed per thread
-    float const sigma = ((x + t) & 1) ? -1.0f : 1.0f;
+    // (-1)^(x+y) of map.comp:60; y = t + T s with T even and xa even: fixed per thread, opposite for xa + 1
+    float const sigma = (t & 1) ? -1.0f : 1.0f;
 
-    float dx[E], dy[E], dz[E];
+    float dxa[E], dya[E], dza[E];
+    float dxb[E], dyb[E], dzb[E];
 
     // height, then choppy x / y displacement: Re(column transform) * sigma [* choppiness] (map.comp:62-64)
     #pragma unroll
     for(int field = 0; field < 3; ++field)
     {
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-        v[s] = spec[field * plane + blocked<N>(t + T * s, x)];
-
-      fft_line<N>(v, t, lines + c * C::CS, midtab, w, true);
+      cf va[E], vb[E];
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
-        if (field == 0) dz[s] = v[s].x * sigma;
-        if (field == 1) dx[s] = v[s].x * sigma * cc.choppiness;
-        if (field == 2) dy[s] = v[s].x * sigma * cc.choppiness;
+        float4 q = *reinterpret_cast<float4 const*>(spec + field * plane + blocked<N>(t + T * s, xa));
+
+        va[s] = cf{ q.x, q.y };
+        vb[s] = cf{ q.z, q.w };
+      }
+
+      fft_line<N>(va, t, lines + cp * C::CS, midtab, w, true);
+      fft_line<N>(vb, t, lines + cp * C::CS, midtab, w, true);
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+        if (field == 0) { dza[s] = va[s].x * sigma; dzb[s] = vb[s].x * -sigma; }
+        if (field == 1) { dxa[s] = va[s].x * sigma * cc.choppiness; dxb[s] = vb[s].x * -sigma * cc.choppiness; }
+        if (field == 2) { dya[s] = va[s].x * sigma * cc.choppiness; dyb[s] = vb[s].x * -sigma * cc.choppiness; }
       }
     }
 
     // exchange heights (the transform lines are free after the last barrier of fft_line)
+    float *owna = dzmain + (2 * cp) * C::SY;
+    float *ownb = owna + C::SY;
+
     #pragma unroll
     for(int s = 0; s < E; ++s)
-      dzmain[c * C::SY + t + T * s] = dz[s];
+    {
+      owna[t + T * s] = dza[s];
+      ownb[t + T * s] = dzb[s];
+    }
 
     __syncthreads();
 
-    float const *left = (c == 0) ? dzhalo : dzmain + (c - 1) * C::SY;
-    float const *right = (c == W - 1) ? dzhalo + C::SY : dzmain + (c + 1) * C::SY;
-    float const *own = dzmain + c * C::SY;
+    float const *left = (cp == 0) ? dzhalo : owna - C::SY;
+    float const *right = (cp == WC - 1) ? dzhalo + C::SY : ownb + C::SY;
 
-    // central-difference normal (map.comp:72-77) and the two image stores (map.comp:79-80)
+    // central-difference normal (map.comp:72-77) and the two image stores (map.comp:79-80), two texels per row
     #pragma unroll
     for(int s = 0; s < E; ++s)
     {
       int y = t + T * s;
+      int yu = (y + N - 1) & (N - 1);
+      int yd = (y + 1) & (N - 1);
 
-      float nx = left[y] - right[y];
-      float ny = own[(y + 1) & (N - 1)] - own[(y + N - 1) & (N - 1)];
       float nz = cc.nz;
 
-      float inv = rsqrtf(nx * nx + ny * ny + nz * nz);
+      float nxa = left[y] - dzb[s];
+      float nya = owna[yd] - owna[yu];
+      float inva = rsqrtf(nxa * nxa + nya * nya + nz * nz);
 
-      layer0[(size_t)y * N + x] = make_float4(dx[s], dy[s], dz[s], 0.0f);
-      layer1[(size_t)y * N + x] = make_float4(nx * inv, ny * inv, nz * inv, 0.0f);
+      float nxb = dza[s] - right[y];
+      float nyb = ownb[yd] - ownb[yu];
+      float invb = rsqrtf(nxb * nxb + nyb * nyb + nz * nz);
+
+      size_t o = (size_t)y * N + xa;
+
+      layer0[o] = make_float4(dxa[s], dya[s], dza[s], 0.0f);
+      layer0[o + 1] = make_float4(dxb[s], dyb[s], dzb[s], 0.0f);
+      layer1[o] = make_float4(nxa * inva, nya * inva, nz * inva, 0.0f);
+      layer1[o + 1] = make_float4(nxb * invb, nyb * invb, nz * invb, 0.0f);
     }
   }
 

@@ -71,8 +71,9 @@ typedef struct datum_ocean_set
 int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int cascades);
 int datum_ocean_destroy(datum_ocean_t ctx);
 
-/* Use the caller's hipStream_t (passed as void*) instead of the handle's own; NULL restores it. */
-int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream);
+/* use_own == 0: enqueue on the caller's hipStream_t (passed as void*; NULL is HIP's default stream).
+ * use_own != 0: back to the handle's own stream.  Drains the stream in use before switching. */
+int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream, int use_own);
 
 /* Let the displacement maps be written into caller-owned DEVICE memory of
  * cascades * 2 * N * N * 4 floats (e.g. a buffer that is later all-gathered); NULL restores the

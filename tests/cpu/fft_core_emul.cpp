@@ -38,10 +38,15 @@ static void run_line(float const *in, float *out)
   auto R = [&](int t) -> cf (&)[P::E] { return *reinterpret_cast<cf (*)[P::E]>(&regs[t*P::E]); };
 
   for(int t = 0; t < P::T; ++t) L::pass0(R(t), t, line.data());
-  if (P::NP == 3)
+  if (P::NP >= 3)
   {
-    for(int t = 0; t < P::T; ++t) L::mid_load(R(t), t, line.data(), midtab.data());
-    for(int t = 0; t < P::T; ++t) L::mid_store(R(t), t, line.data());
+    for(int t = 0; t < P::T; ++t) L::template mid_load<1>(R(t), t, line.data(), midtab.data(), w[t]);
+    for(int t = 0; t < P::T; ++t) L::template mid_store<1>(R(t), t, line.data());
+  }
+  if (P::NP >= 4)
+  {
+    for(int t = 0; t < P::T; ++t) L::template mid_load<2>(R(t), t, line.data(), midtab.data(), w[t]);
+    for(int t = 0; t < P::T; ++t) L::template mid_store<2>(R(t), t, line.data());
   }
   for(int t = 0; t < P::T; ++t) L::last(R(t), t, line.data(), w[t]);
 

@@ -263,9 +263,13 @@ def test_linearity_at_full_size(capi, oracle, N):
             outs.append(oc.read_maps(0)[0, ..., :3].astype(np.float64))
     assert np.isfinite(outs[2]).all()
     assert rmse(outs[2], outs[0] + 2 * outs[1]) < 2e-6
-    # mean of dz over the grid is the k=0 bin of sigma-modulated h~ ... checked instead: sum of dz equals
-    # N*N * Re(h~ at index (N/2, N/2)) == 0 because h0 there is 0 (phillips(0) = 0, ocean.cpp:91-92)
-    assert abs(outs[0][..., 2].mean()) < 1e-6
+    # checksum: the grid mean of dz is the centred-k zero bin of h~, index (N/2, N/2).  h0 is 0 there
+    # (phillips(0) = 0, ocean.cpp:91-92) but its sim.comp:59 partner (N/2-1, N/2-1) is not:
+    # mean(dz) = Re(conj(h0[N/2-1, N/2-1]) * exp(-i phase[N/2, N/2]))
+    m = a[N // 2 - 1, N // 2 - 1].astype(np.float64)
+    ph = float(phase[N // 2, N // 2])
+    want_mean = m[0] * np.cos(ph) - m[1] * np.sin(ph)
+    assert abs(outs[0][..., 2].mean() - want_mean) < 1e-6
 
 
 def test_idempotent_without_update(capi, oracle):
@@ -356,4 +360,4 @@ def test_bound_maps_and_caller_stream(capi, oracle, torch):
         stream.synchronize()
         assert np.array_equal(buf.cpu().numpy().reshape(2, N, N, 4), own)
         oc.bind_maps(0, 0)
-        oc.set_stream(0)
+        oc.set_stream(None)

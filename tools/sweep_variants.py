@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Runs bench.py (no CPU leg) and a 1024^2 parity spot check for every variant in datum_amd/lib/variants/."""
+import glob, json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+extra = sys.argv[1:]
+rows = []
+for lib in sorted(glob.glob(os.path.join(ROOT, "datum_amd/lib/variants/lib_*.so"))):
+    env = dict(os.environ, DATUM_OCEAN_HIP_LIB=lib)
+    name = os.path.basename(lib)[4:-3]
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "10", "--cpu-seconds", "0"] + extra,
+                             env=env, capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            print(name, "FAILED", out.stderr[-400:]); continue
+        j = json.loads(line[-1]); r = j["roofline"]
+        chk = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(ROOT, "tests/test_gpu_parity.py"),
+                              "-k", "test_displace_end_to_end and 1024 or test_golden"], env=env, capture_output=True, text=True, timeout=600)
+        ok = chk.stdout.strip().splitlines()[-1] if chk.stdout.strip() else "?"
+        print(f"{name:28s} grids/s {j['value']:9.0f}  step {j['ms_per_step']*1e3:7.1f} us  row {r['rowpass']['ms']*1e3:7.1f} us {r['rowpass']['GBps']:6.0f} GB/s  "
+              f"col {r['colpass']['ms']*1e3:7.1f} us {r['colpass']['GBps']:6.0f} GB/s  step_frac {r['step_frac']:.3f}  parity: {ok}", flush=True)
+    except Exception as e:
+        print(name, "ERROR", e)
