@@ -31,6 +31,9 @@ struct datum_ocean_ctx
   float4 *maps = nullptr;             // the one in use
   float4 *ownmaps = nullptr;
   cf *tw = nullptr;
+  float *omega = nullptr;             // [cascade][(N/2+1)^2] dispersion quadrant, rebuilt when a wavescale changes
+  float *wavescales = nullptr;        // [MAX_CASCADES] device copy for the table build
+  bool omegadirty = true;
   cf *scratch = nullptr;              // 3 row-major planes for the debug read-backs (lazy)
 
   CascadeConst casc[DATUM_OCEAN_MAX_CASCADES];
@@ -86,6 +89,7 @@ namespace
     a.spec = ctx->spec;
     a.maps = ctx->maps;
     a.tw = ctx->tw;
+    a.omega = ctx->omega;
     a.ndt = ndt;
     for(int i = 0; i < MAX_PENDING; ++i)
       a.dt[i] = (i < ndt) ? dt[i] : 0.0f;
@@ -94,14 +98,16 @@ namespace
   }
 
   template<int N>
-  hipError_t configure()
+  hipError_t configure(char const **what)
   {
     hipError_t e;
 
+    *what = "hipFuncSetAttribute(ocean_rowpass_kernel, MaxDynamicSharedMemorySize)";
     e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS);
     if (e != hipSuccess)
       return e;
 
+    *what = "hipFuncSetAttribute(ocean_colpass_kernel, MaxDynamicSharedMemorySize)";
     return hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
   }
 
@@ -134,9 +140,37 @@ namespace
       case 4096: { constexpr int NN = 4096; expr; } break; \
     }
 
+  // (re)build the dispersion quadrant tables after a wavescale change
+  int ensure_omega(datum_ocean_ctx *ctx)
+  {
+    if (!ctx->omegadirty)
+      return DATUM_OCEAN_OK;
+
+    float ws[DATUM_OCEAN_MAX_CASCADES];
+    for(int c = 0; c < DATUM_OCEAN_MAX_CASCADES; ++c)
+      ws[c] = ctx->casc[c].wavescale;
+
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->wavescales, ws, sizeof(ws), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));   // ws lives on this stack frame
+
+    hipLaunchKernelGGL(ocean_omega_kernel, dim3(512), dim3(256), 0, ctx->stream, ctx->omega, ctx->N, ctx->cascades, ctx->wavescales);
+    HIPCHECK(ctx, hipGetLastError());
+
+    ctx->omegadirty = false;
+
+    return DATUM_OCEAN_OK;
+  }
+
   // flush queued updates that do not fit into one displace call
   int flush_pending(datum_ocean_ctx *ctx, size_t keep)
   {
+    if (ctx->pending.size() > keep)
+    {
+      int rc = ensure_omega(ctx);
+      if (rc != DATUM_OCEAN_OK)
+        return rc;
+    }
+
     while (ctx->pending.size() > keep)
     {
       int n = (int)std::min<size_t>(MAX_PENDING, ctx->pending.size() - keep);
@@ -200,6 +234,8 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
   CREATECHECK(hipMalloc(&ctx->spec, cascades * 3 * P * sizeof(cf)));
   CREATECHECK(hipMalloc(&ctx->ownmaps, cascades * 2 * P * sizeof(float4)));
   CREATECHECK(hipMalloc(&ctx->tw, resolution * sizeof(cf)));
+  CREATECHECK(hipMalloc(&ctx->omega, (size_t)cascades * (resolution / 2 + 1) * (resolution / 2 + 1) * sizeof(float)));
+  CREATECHECK(hipMalloc(&ctx->wavescales, DATUM_OCEAN_MAX_CASCADES * sizeof(float)));
   ctx->maps = ctx->ownmaps;
 
   CREATECHECK(hipMemsetAsync(ctx->h0, 0, cascades * P * sizeof(float2), ctx->stream));
@@ -231,9 +267,19 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
     ctx->casc[c].nz = 4 / (ctx->casc[c].scale * resolution);
   }
 
-  hipError_t ce = hipSuccess;
-  DISPATCH_N(resolution, ce = configure<NN>());
-  CREATECHECK(ce);
+  {
+    hipError_t ce = hipSuccess;
+    char const *what = "";
+    DISPATCH_N(resolution, ce = configure<NN>(&what));
+    if (ce != hipSuccess)
+    {
+      char buf[256];
+      snprintf(buf, sizeof(buf), "%s [row %zu B, col %zu B]", what, (size_t)0, (size_t)0);
+      int rc = fail(nullptr, (int)ce, what);
+      datum_ocean_destroy(ctx);
+      return rc;
+    }
+  }
 
   CREATECHECK(hipStreamSynchronize(ctx->stream));
 
@@ -265,6 +311,8 @@ int datum_ocean_destroy(datum_ocean_t ctx)
   (void)hipFree(ctx->spec);
   (void)hipFree(ctx->ownmaps);
   (void)hipFree(ctx->tw);
+  (void)hipFree(ctx->omega);
+  (void)hipFree(ctx->wavescales);
   (void)hipFree(ctx->scratch);
 
   if (ctx->ownstream)
@@ -343,6 +391,9 @@ int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, flo
   }
 
   CascadeConst &cc = ctx->casc[cascade];
+
+  if (cc.wavescale != wavescale)
+    ctx->omegadirty = true;
 
   cc.wavescale = wavescale;
   cc.scale = 1 / wavescale;                      // ocean.cpp:743
@@ -434,6 +485,8 @@ int datum_ocean_displace(datum_ocean_t ctx)
   HIPCHECK(ctx, hipSetDevice(ctx->device));
 
   int rc = flush_pending(ctx, MAX_PENDING);
+  if (rc == DATUM_OCEAN_OK && !ctx->pending.empty())
+    rc = ensure_omega(ctx);
   if (rc != DATUM_OCEAN_OK)
     return rc;
 

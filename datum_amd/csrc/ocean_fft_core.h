@@ -47,8 +47,7 @@ namespace ocean
   constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
 
   // N = E^(NP-1) * RL: NP-1 passes of radix E, one last pass of radix RL <= E done as M = E/RL tasks.
-  // E = 8 keeps a line transform near 50 VGPRs (E = 16: ~90), which is what lets two 1024-thread
-  // workgroups share a CU without spilling; 4096 uses E = 16 to stay within 1024 threads per tile.
+  // E = 8 keeps a line transform near 50 VGPRs (E = 16: ~90) so that several lines per thread fit in registers.
   constexpr int plan_passes(int n, int e) { return n <= e ? 1 : 1 + plan_passes(n / e, e); }
 
   template<int N>
@@ -56,7 +55,7 @@ namespace ocean
   {
     static_assert(N == 64 || N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096, "unsupported resolution");
 
-    static constexpr int E = (N == 64) ? 4 : (N == 4096) ? 16 : 8;
+    static constexpr int E = (N == 64) ? 4 : 8;
     static constexpr int T = N / E;
     static constexpr int NP = plan_passes(N, E);
     static constexpr int RL = N / ipow(E, NP - 1);

@@ -44,6 +44,7 @@ namespace ocean
     cf *spec;            // [cascade][3][N*N]    Spectrum::h, hx, hy (blocked layout)
     float4 *maps;        // [cascade][2][N*N]    displacementmap, 2 layers RGBA32F
     cf const *tw;        // [N]                  exp(+2 pi i k / N)
+    float const *omega;  // [cascade][(N/2+1)^2] dispersion(k) by (|m - N/2|, |n - N/2|)
     int ndt;
     float dt[MAX_PENDING];
     CascadeConst casc[DATUM_OCEAN_MAX_CASCADES];
@@ -68,6 +69,38 @@ namespace ocean
     return sqrtf((9.81f * sqrtf(k2)) * (1.0f + k2 / 136900.0f));
   }
 
+  // dispersion(k) depends on |kx|, |ky| only and x -> -x is exact in fp32, so one quadrant of it, built once per
+  // wavescale with the formula above, serves every step: omega[i * (N/2+1) + j] = dispersion at |m - N/2| = i,
+  // |n - N/2| = j.  The row pass then pays one L2-resident load instead of two IEEE divides and two IEEE
+  // square roots per point, and the phase it produces is still bit-identical to update_ocean's.
+  __global__ void ocean_omega_kernel(float *omega, int N, int cascades, float const *wavescales)
+  {
+    int const Q = N / 2 + 1;
+
+    for(int cascade = 0; cascade < cascades; ++cascade)
+    {
+      float const wavescale = wavescales[cascade];
+      float *table = omega + (size_t)cascade * Q * Q;
+
+      for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < (size_t)Q * Q; k += (size_t)gridDim.x * blockDim.x)
+      {
+        int i = (int)(k / Q), j = (int)(k % Q);
+
+        table[k] = dispersion_at(N / 2 + j, N / 2 + i, N, wavescale);
+      }
+    }
+  }
+
+  __device__ __forceinline__ float dispersion_lookup(float const *table, int n, int m, int N)
+  {
+    int j = n - N / 2, i = m - N / 2;
+
+    j = j < 0 ? -j : j;
+    i = i < 0 ? -i : i;
+
+    return table[i * (N / 2 + 1) + j];
+  }
+
   // fmod(phase + w*dt, 2 pi) of ocean.cpp:231.  fmod is exact; for 2pi <= a < 4pi it is a - 2pi (exact, Sterbenz)
   __device__ __forceinline__ float advance_phase(float phase, float wdt)
   {
@@ -86,11 +119,37 @@ namespace ocean
 
   //|---------------------- ocean.sim -----------------------------------------
 
+  // sin and cos of the phase (sim.comp:61-62).  update_ocean keeps the phase in [0, 2 pi), so the argument
+  // reduction is a two-constant Cody-Waite step to [-pi/4, pi/4] followed by the Cephes single-precision
+  // minimax polynomials: about 1 ulp there (measured against float64 in tests), at a quarter of the
+  // instructions and registers of the all-range libm path.  Arguments far outside (|x| >> 1e4) lose accuracy
+  // gradually, as GLSL's own sin/cos do.
+  __device__ __forceinline__ void sincos_phase(float x, float *sin_out, float *cos_out)
+  {
+    float k = rintf(x * 0.636619772367581343f);                 // x * 2/pi
+
+    float r = fmaf(k, -1.57079637050628662109375f, x);          // pi/2 head
+    r = fmaf(k, 4.37113900018624283e-8f, r);                    // pi/2 tail
+
+    float z = r * r;
+
+    float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(z, -0.5f, 1.0f));
+
+    int q = (int)k;
+
+    float s = (q & 1) ? cp : sp;
+    float c = (q & 1) ? sp : cp;
+
+    *sin_out = (q & 2) ? -s : s;
+    *cos_out = ((q + 1) & 2) ? -c : c;
+  }
+
   // one point of data/ocean.sim.comp:52-66: h~ from h0(k), h0 at the mirror index and the phase
   __device__ __forceinline__ cf sim_height(float2 h0k, float2 h0mk, float phase)
   {
     float sin_v, cos_v;
-    sincosf(phase, &sin_v, &cos_v);
+    sincos_phase(phase, &sin_v, &cos_v);
 
     cf h;
     h.x = (h0k.x + h0mk.x) * cos_v - (h0k.y + h0mk.y) * sin_v;
@@ -105,35 +164,56 @@ namespace ocean
     return (6.2831855f * ((float)i - 0.5f * (float)N)) * scale;
   }
 
-  __device__ __forceinline__ float2 knorm_of(float kx, float ky)
+  // 1 / |k|, 0 at k = 0: normalize(k) = k * inversesqrt(dot(k, k)) with the k = 0 guard of sim.comp:54
+  __device__ __forceinline__ float kinv_of(float kx, float ky)
   {
     float k2 = kx * kx + ky * ky;
-    float inv = (k2 != 0.0f) ? rsqrtf(k2) : 0.0f;
+
+    return (k2 != 0.0f) ? rsqrtf(k2) : 0.0f;
+  }
+
+  __device__ __forceinline__ float2 knorm_of(float kx, float ky)
+  {
+    float inv = kinv_of(kx, ky);
 
     return make_float2(kx * inv, ky * inv);
   }
 
-  //|---------------------- line FFT with workgroup barriers ------------------
+  //|---------------------- line FFTs with workgroup barriers ------------------
+  // K independent lines per thread go through the exchange phases together, so the number of barriers per
+  // workgroup does not grow with K (one line per barrier phase is what the reference's per-field loop does).
 
-  template<int N>
-  __device__ __forceinline__ void fft_line(cf (&v)[Plan<N>::E], int t, cf *line, cf const *midtab, typename LineFFT<N>::Twiddles const &w, bool active)
+  template<int N, int K>
+  __device__ __forceinline__ void fft_lines(cf (&v)[K][Plan<N>::E], int t, cf *line, int linestride, cf const *midtab, typename LineFFT<N>::Twiddles const &w, bool active)
   {
     typedef LineFFT<N> L;
 
     if (active)
-      L::pass0(v, t, line);
+    {
+      #pragma unroll
+      for(int k = 0; k < K; ++k)
+        L::pass0(v[k], t, line + k * linestride);
+    }
 
     __syncthreads();
 
     if (Plan<N>::NP >= 3)
     {
       if (active)
-        L::template mid_load<1>(v, t, line, midtab, w);
+      {
+        #pragma unroll
+        for(int k = 0; k < K; ++k)
+          L::template mid_load<1>(v[k], t, line + k * linestride, midtab, w);
+      }
 
       __syncthreads();
 
       if (active)
-        L::template mid_store<1>(v, t, line);
+      {
+        #pragma unroll
+        for(int k = 0; k < K; ++k)
+          L::template mid_store<1>(v[k], t, line + k * linestride);
+      }
 
       __syncthreads();
     }
@@ -141,18 +221,30 @@ namespace ocean
     if (Plan<N>::NP >= 4)
     {
       if (active)
-        L::template mid_load<2>(v, t, line, midtab, w);
+      {
+        #pragma unroll
+        for(int k = 0; k < K; ++k)
+          L::template mid_load<2>(v[k], t, line + k * linestride, midtab, w);
+      }
 
       __syncthreads();
 
       if (active)
-        L::template mid_store<2>(v, t, line);
+      {
+        #pragma unroll
+        for(int k = 0; k < K; ++k)
+          L::template mid_store<2>(v[k], t, line + k * linestride);
+      }
 
       __syncthreads();
     }
 
     if (active)
-      L::last(v, t, line, w);
+    {
+      #pragma unroll
+      for(int k = 0; k < K; ++k)
+        L::last(v[k], t, line + k * linestride, w);
+    }
 
     __syncthreads();
   }
@@ -160,48 +252,75 @@ namespace ocean
   //|---------------------- row pass ------------------------------------------
 
 #ifndef OCEAN_ROW_THREADS
-#define OCEAN_ROW_THREADS 512
+#define OCEAN_ROW_THREADS 256
 #endif
 #ifndef OCEAN_ROW_MINWAVES
-#define OCEAN_ROW_MINWAVES 6
+#define OCEAN_ROW_MINWAVES 1
+#endif
+#ifndef OCEAN_ROW_FIELDS
+#define OCEAN_ROW_FIELDS 3          // fields per barrier phase: 1 or 3
 #endif
 #ifndef OCEAN_COL_THREADS
 #define OCEAN_COL_THREADS 512
 #endif
 #ifndef OCEAN_COL_MINWAVES
-#define OCEAN_COL_MINWAVES 4
+#define OCEAN_COL_MINWAVES 1
 #endif
 
   template<int N>
   struct RowCfg
   {
     static constexpr int T = Plan<N>::T;
+    static constexpr int K = OCEAN_ROW_FIELDS;
     static constexpr int ROWS = (OCEAN_ROW_THREADS / T) < 1 ? 1 : (OCEAN_ROW_THREADS / T) > 8 ? 8 : (OCEAN_ROW_THREADS / T);
     static constexpr int THREADS = ROWS * T;
-    static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_ROW_MINWAVES : 4;        // per SIMD
-    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)ROWS * Plan<N>::LINE) * sizeof(cf);
+    static constexpr int GROUPS = N / ROWS;                                            // workgroups per cascade
+    static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_ROW_MINWAVES : 1;        // per SIMD
+    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)ROWS * K * Plan<N>::LINE) * sizeof(cf);
+
+    static_assert(K == 1 || K == 3, "OCEAN_ROW_FIELDS must be 1 or 3");
   };
+
+  // Which row group a workgroup takes.  Blocks are dealt round-robin over the 8 XCDs (blockIdx.x % 8, speed
+  // only): each XCD gets a band of row groups together with the mirrored band, because row y reads h0 of row
+  // N-1-y (sim.comp:59) and the dispersion row |y - N/2|, so both come out of that XCD's L2 the second time.
+  template<int N>
+  __device__ __forceinline__ int rowgroup_of_block(int b)
+  {
+    constexpr int G = RowCfg<N>::GROUPS;
+
+    if (G % 16 != 0)
+      return b;
+
+    int xcd = b & 7;
+    int slot = b >> 3;
+    int pair = xcd * (G / 16) + (slot >> 1);
+
+    return (slot & 1) ? (G - 1 - pair) : pair;
+  }
 
   template<int N>
   __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MINWAVES) ocean_rowpass_kernel(StepArgs a)
   {
     typedef Plan<N> P;
     typedef LineFFT<N> L;
+    typedef RowCfg<N> C;
 
     constexpr int E = P::E;
     constexpr int T = P::T;
+    constexpr int K = C::K;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     int const cascade = blockIdx.y;
     int const r = threadIdx.x / T;
     int const t = threadIdx.x % T;
-    int const y = blockIdx.x * RowCfg<N>::ROWS + r;
+    int const y = rowgroup_of_block<N>(blockIdx.x) * C::ROWS + r;
 
     cf *midtab = reinterpret_cast<cf*>(smem);
-    cf *line = midtab + L::MIDTAB + r * P::LINE;
+    cf *line = midtab + L::MIDTAB + r * K * P::LINE;
 
-    for(int i = threadIdx.x; i < L::MIDTAB; i += RowCfg<N>::THREADS)
+    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
       midtab[i] = L::midtab_entry(a.tw, i);
 
     CascadeConst const cc = a.casc[cascade];
@@ -211,90 +330,107 @@ namespace ocean
     float2 const *h0 = a.h0 + cascade * plane;
     float *phase = a.phase + cascade * plane;
     cf *spec = a.spec + cascade * 3 * plane;
+    float const *omega = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
 
-    // ocean.sim for this row, CH points at a time to bound the registers in flight: this row of h0
-    // and phase, and the -k partner row read backwards (sim.comp:59: index (N-1-y, N-1-x)).
-    // update_ocean (ocean.cpp:223-233) is applied on the way, each pending dt in turn.
-    constexpr int CH = (E < 4) ? E : 4;
+    float const ky = wavevector(y, N, cc.scale);
 
+    // ocean.sim for this row: this row of h0 and phase, and the -k partner row read backwards
+    // (sim.comp:59: index (N-1-y, N-1-x)).  update_ocean (ocean.cpp:223-233) is applied on the way,
+    // each pending dt in turn.
     cf h[E];
+    float kinv[E];
 
-    #pragma unroll
-    for(int s0 = 0; s0 < E; s0 += CH)
     {
-      float ph[CH];
-      float2 hk[CH], hm[CH];
+      float ph[E], om[E];
+      float2 hk[E], hm[E];
 
       #pragma unroll
-      for(int i = 0; i < CH; ++i)
+      for(int s = 0; s < E; ++s)
       {
-        int x = t + T * (s0 + i);
+        int x = t + T * s;
 
-        ph[i] = phase[(size_t)y * N + x];
-        hk[i] = h0[(size_t)y * N + x];
-        hm[i] = h0[(size_t)(N - 1 - y) * N + (N - 1 - x)];
+        ph[s] = phase[(size_t)y * N + x];
+        hk[s] = h0[(size_t)y * N + x];
+        hm[s] = h0[(size_t)(N - 1 - y) * N + (N - 1 - x)];
       }
 
       if (a.ndt > 0)
       {
         #pragma unroll
-        for(int i = 0; i < CH; ++i)
+        for(int s = 0; s < E; ++s)
+          om[s] = dispersion_lookup(omega, t + T * s, y, N);
+
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
         {
-          int x = t + T * (s0 + i);
-
-          float omega = dispersion_at(x, y, N, cc.wavescale);
-
-          float p = ph[i];
+          float p = ph[s];
           for(int k = 0; k < a.ndt; ++k)
-            p = advance_phase(p, omega * a.dt[k]);
+            p = advance_phase(p, om[s] * a.dt[k]);
 
-          ph[i] = p;
-          phase[(size_t)y * N + x] = p;
+          ph[s] = p;
+          phase[(size_t)y * N + t + T * s] = p;
         }
       }
 
       #pragma unroll
-      for(int i = 0; i < CH; ++i)
-        h[s0 + i] = sim_height(hk[i], hm[i], ph[i]);
-
-      __builtin_amdgcn_sched_barrier(0);
+      for(int s = 0; s < E; ++s)
+      {
+        h[s] = sim_height(hk[s], hm[s], ph[s]);
+        kinv[s] = kinv_of(wavevector(t + T * s, N, cc.scale), ky);
+      }
     }
 
     typename L::Twiddles w;
     L::load_twiddles(a.tw, t, w);
 
-    // hx = -i h k^x, hy = -i h k^y (sim.comp:68-74), then h itself; each through the row transform
-    #pragma unroll
-    for(int field = 1; field <= 2; ++field)
+    // hx = -i h k^x, hy = -i h k^y (sim.comp:68-74) and h itself, each through the row transform
+    if (K == 3)
     {
-      // k^ is recomputed per field rather than kept across a transform (registers)
-      float ky = wavevector(y, N, cc.scale);
-      asm volatile("" : "+v"(ky));
-
-      cf v[E];
+      cf v[K][E];
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
-        float2 kn = knorm_of(wavevector(t + T * s, N, cc.scale), ky);
-        float kc = (field == 1) ? kn.x : kn.y;
+        float kx = wavevector(t + T * s, N, cc.scale) * kinv[s];
+        float kyn = ky * kinv[s];
 
-        v[s].x = h[s].y * kc;
-        v[s].y = -h[s].x * kc;
+        v[0][s] = h[s];
+        v[1 % K][s] = cf{ h[s].y * kx, -h[s].x * kx };
+        v[2 % K][s] = cf{ h[s].y * kyn, -h[s].x * kyn };
       }
 
-      fft_line<N>(v, t, line, midtab, w, true);
+      fft_lines<N, K>(v, t, line, P::LINE, midtab, w, true);
 
       #pragma unroll
-      for(int s = 0; s < E; ++s)
-        spec[field * plane + blocked<N>(y, t + T * s)] = v[s];
+      for(int field = 0; field < K; ++field)
+      {
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+          spec[field * plane + blocked<N>(y, t + T * s)] = v[field][s];
+      }
     }
+    else
+    {
+      #pragma unroll
+      for(int field = 2; field >= 0; --field)
+      {
+        cf v[1][E];
 
-    fft_line<N>(h, t, line, midtab, w, true);
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+        {
+          float kc = ((field == 1) ? wavevector(t + T * s, N, cc.scale) : ky) * kinv[s];
 
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-      spec[blocked<N>(y, t + T * s)] = h[s];
+          v[0][s] = (field == 0) ? h[s] : cf{ h[s].y * kc, -h[s].x * kc };
+        }
+
+        fft_lines<N, 1>(v, t, line, P::LINE, midtab, w, true);
+
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+          spec[field * plane + blocked<N>(y, t + T * s)] = v[0][s];
+      }
+    }
   }
 
   //|---------------------- column pass + map ---------------------------------
@@ -303,18 +439,18 @@ namespace ocean
   struct ColCfg
   {
     static constexpr int T = Plan<N>::T;
-    static constexpr int WC = (OCEAN_COL_THREADS / T) < 1 ? 1 : (OCEAN_COL_THREADS / T) > 8 ? 8 : (OCEAN_COL_THREADS / T);   // columns in flight
+    static constexpr int WC = (OCEAN_COL_THREADS / T) < 1 ? 1 : (OCEAN_COL_THREADS / T) > 8 ? 8 : (OCEAN_COL_THREADS / T);   // column pairs in flight
     static constexpr int W = 2 * WC;                                    // tile width: two adjacent columns per thread
     static constexpr int THREADS = WC * T;
-    static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_COL_MINWAVES : 4;
-    static constexpr int CS = Plan<N>::LINE + 2;                        // LDS column stride (complex), == 2 mod 16
+    static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_COL_MINWAVES : 1;
+    static constexpr int CS = Plan<N>::LINE + 2;                        // LDS line stride (complex), == 2 mod 16
     static constexpr int SY = N + 4;                                    // height exchange: column stride (floats)
 
-    // LDS carve, in bytes: first middle-pass twiddles | heights of the two halo columns | transform lines,
-    // later reused for the heights of the tile's own columns
+    // LDS carve, in bytes: first middle-pass twiddles | heights of the two halo columns | 2 WC transform lines
+    // (both columns of every pair are in flight), later reused for the heights of the tile's own columns
     static constexpr size_t OFF_HALO = (size_t)LineFFT<N>::MIDTAB * sizeof(cf);
     static constexpr size_t OFF_MAIN = OFF_HALO + (size_t)2 * SY * sizeof(float);
-    static constexpr size_t MAIN_FFT = (size_t)WC * CS * sizeof(cf);
+    static constexpr size_t MAIN_FFT = (size_t)2 * WC * CS * sizeof(cf);
     static constexpr size_t MAIN_DZ = (size_t)W * SY * sizeof(float);
     static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
 
@@ -338,7 +474,7 @@ namespace ocean
 
     cf *midtab = reinterpret_cast<cf*>(smem);
     float *dzhalo = reinterpret_cast<float*>(smem + C::OFF_HALO);     // [2][SY]: columns x0 - 1 and x0 + W
-    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [WC][CS]
+    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [2 WC][CS]
     float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [W][SY], after the transforms
 
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
@@ -355,8 +491,8 @@ namespace ocean
     float4 *layer0 = a.maps + (size_t)cascade * 2 * plane;
     float4 *layer1 = layer0 + plane;
 
-    // halo rounds first (nothing else is live yet): height of the two columns bordering the tile
-    // (periodic, map.comp:58).  Column slot hc = thread / T, row group ht = thread % T.
+    // halo round first (nothing else is live yet): height of the two columns bordering the tile
+    // (periodic, map.comp:58).  Line slot hc = thread / T (2 WC >= 2 of them), row group ht = thread % T.
     {
       int const hc = threadIdx.x / T;
       int const ht = threadIdx.x % T;
@@ -372,22 +508,22 @@ namespace ocean
         int const hx = (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
         float const hsigma = ((hx + ht) & 1) ? -1.0f : 1.0f;
 
-        cf v[E];
+        cf v[1][E];
 
         if (halo)
         {
           #pragma unroll
           for(int s = 0; s < E; ++s)
-            v[s] = spec[blocked<N>(ht + T * s, hx)];
+            v[0][s] = spec[blocked<N>(ht + T * s, hx)];
         }
 
-        fft_line<N>(v, ht, lines + hc * C::CS, midtab, hw, halo);
+        fft_lines<N, 1>(v, ht, lines + hc * C::CS, C::CS, midtab, hw, halo);
 
         if (halo)
         {
           #pragma unroll
           for(int s = 0; s < E; ++s)
-            dzhalo[side * C::SY + ht + T * s] = v[s].x * hsigma;
+            dzhalo[side * C::SY + ht + T * s] = v[0][s].x * hsigma;
         }
       }
     }
@@ -410,30 +546,29 @@ namespace ocean
     #pragma unroll
     for(int field = 0; field < 3; ++field)
     {
-      cf va[E], vb[E];
+      cf v[2][E];
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
         float4 q = *reinterpret_cast<float4 const*>(spec + field * plane + blocked<N>(t + T * s, xa));
 
-        va[s] = cf{ q.x, q.y };
-        vb[s] = cf{ q.z, q.w };
+        v[0][s] = cf{ q.x, q.y };
+        v[1][s] = cf{ q.z, q.w };
       }
 
-      fft_line<N>(va, t, lines + cp * C::CS, midtab, w, true);
-      fft_line<N>(vb, t, lines + cp * C::CS, midtab, w, true);
+      fft_lines<N, 2>(v, t, lines + 2 * cp * C::CS, C::CS, midtab, w, true);
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
-        if (field == 0) { dza[s] = va[s].x * sigma; dzb[s] = vb[s].x * -sigma; }
-        if (field == 1) { dxa[s] = va[s].x * sigma * cc.choppiness; dxb[s] = vb[s].x * -sigma * cc.choppiness; }
-        if (field == 2) { dya[s] = va[s].x * sigma * cc.choppiness; dyb[s] = vb[s].x * -sigma * cc.choppiness; }
+        if (field == 0) { dza[s] = v[0][s].x * sigma; dzb[s] = v[1][s].x * -sigma; }
+        if (field == 1) { dxa[s] = v[0][s].x * sigma * cc.choppiness; dxb[s] = v[1][s].x * -sigma * cc.choppiness; }
+        if (field == 2) { dya[s] = v[0][s].x * sigma * cc.choppiness; dyb[s] = v[1][s].x * -sigma * cc.choppiness; }
       }
     }
 
-    // exchange heights (the transform lines are free after the last barrier of fft_line)
+    // exchange heights (the transform lines are free after the last barrier of fft_lines)
     float *owna = dzmain + (2 * cp) * C::SY;
     float *ownb = owna + C::SY;
 
@@ -485,13 +620,13 @@ namespace ocean
     size_t const plane = (size_t)N * N;
 
     float *phase = a.phase + cascade * plane;
-    float const wavescale = a.casc[cascade].wavescale;
+    float const *table = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
 
     for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x)
     {
       int m = (int)(i / N), n = (int)(i % N);
 
-      float omega = dispersion_at(n, m, N, wavescale);
+      float omega = dispersion_lookup(table, n, m, N);
 
       float p = phase[i];
       for(int k = 0; k < a.ndt; ++k)
