@@ -28,7 +28,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-CASCADE_WAVESCALES = (22.0, 64.0, 176.0, 512.0)
 DT = np.float32(1.0 / 60.0)
 
 
@@ -41,6 +40,7 @@ def parse():
     ap.add_argument("--cascades", type=int, default=4)
     ap.add_argument("--gather", choices=("batch", "none"), default="batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
+    ap.add_argument("--no-check", action="store_true", help="skip the output sanity check (timing-only ablation builds)")
     return ap.parse_args()
 
 
@@ -90,7 +90,7 @@ def main():
 
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from datum_amd import capi, host_api
+    from datum_amd import capi, farm, host_api
 
     N, C = args.resolution, args.cascades
     dev = torch.device("cuda", local_rank)
@@ -98,11 +98,10 @@ def main():
     # state: this rank's cascades, seeded on the host exactly as seed_ocean does (mt19937(1000 + global index))
     oc = capi.Ocean(N, C, device=local_rank)
     states = []
-    for c in range(C):
-        g = rank * C + c
-        ws = CASCADE_WAVESCALES[c % len(CASCADE_WAVESCALES)]
+    for c, g in enumerate(farm.owned_grids(rank, world, C)):
+        ws = farm.grid_wavescale(g, C)
         p = host_api.OceanParams(N, **dict(host_api.EXAMPLE_TUNABLES, wavescale=ws))
-        p.seed_ocean(1000 + g)
+        p.seed_ocean(farm.grid_seed(g))
         oc.set_cascade(c, ws, 1.35)
         oc.upload_state(c, p.height)
         if rank == 0 and world == 1:
@@ -124,7 +123,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if gathered is not None:
-        dist.all_gather_into_tensor(gathered, maps)
+        farm.gather_maps(maps, world, out=gathered)
 
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -140,7 +139,7 @@ def main():
         step()
     ev1.record(stream)
     if gathered is not None:
-        dist.all_gather_into_tensor(gathered, maps)
+        farm.gather_maps(maps, world, out=gathered)
     ev2.record(stream)
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -160,7 +159,8 @@ def main():
     if rank == 0:
         # sanity: the maps of the last step are finite and non-trivial
         chk = maps[: 2 * N * N * 4].view(2, N, N, 4)
-        assert bool(torch.isfinite(chk).all()) and float(chk[0, ..., 2].abs().max()) > 0
+        if not args.no_check:
+            assert bool(torch.isfinite(chk).all()) and float(chk[0, ..., 2].abs().max()) > 0
 
         grids = args.steps * C * world
         row_b, col_b = oc.algorithmic_bytes()

@@ -34,6 +34,8 @@ struct datum_ocean_ctx
   float *omega = nullptr;             // [cascade][(N/2+1)^2] dispersion quadrant, rebuilt when a wavescale changes
   float *wavescales = nullptr;        // [MAX_CASCADES] device copy for the table build
   bool omegadirty = true;
+  float omegamax[DATUM_OCEAN_MAX_CASCADES] = {};   // largest dispersion of each cascade (table corner)
+  bool wildphase[DATUM_OCEAN_MAX_CASCADES] = {};   // an uploaded phase lies outside [0, 2 pi)
   cf *scratch = nullptr;              // 3 row-major planes for the debug read-backs (lazy)
 
   CascadeConst casc[DATUM_OCEAN_MAX_CASCADES];
@@ -114,7 +116,7 @@ namespace
   template<int N>
   hipError_t launch_rowpass(datum_ocean_ctx *ctx, StepArgs &a)
   {
-    dim3 grid(N / RowCfg<N>::ROWS, ctx->cascades);
+    dim3 grid(RowCfg<N>::BLOCKS, ctx->cascades);
     void *args[] = { &a };
 
     return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), grid, dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream);
@@ -148,7 +150,14 @@ namespace
 
     float ws[DATUM_OCEAN_MAX_CASCADES];
     for(int c = 0; c < DATUM_OCEAN_MAX_CASCADES; ++c)
+    {
       ws[c] = ctx->casc[c].wavescale;
+
+      // dispersion grows with |k|: its maximum is the table corner |m - N/2| = |n - N/2| = N/2 (same fp32 formula)
+      float kc = (6.2831855f * (0.5f * (float)ctx->N)) / ws[c];
+      float k2 = kc * kc + kc * kc;
+      ctx->omegamax[c] = sqrtf((9.81f * sqrtf(k2)) * (1.0f + k2 / 136900.0f));
+    }
 
     HIPCHECK(ctx, hipMemcpyAsync(ctx->wavescales, ws, sizeof(ws), hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));   // ws lives on this stack frame
@@ -159,6 +168,25 @@ namespace
     ctx->omegadirty = false;
 
     return DATUM_OCEAN_OK;
+  }
+
+  // The fused row pass advances the phase with a single conditional subtraction, exact only while
+  // 0 <= phase < 2 pi and 0 <= dispersion * dt < 2 pi.  Anything else goes through the phase-only kernel.
+  bool fusable(datum_ocean_ctx *ctx)
+  {
+    for(int c = 0; c < ctx->cascades; ++c)
+    {
+      if (ctx->wildphase[c])
+        return false;
+
+      for(float dt : ctx->pending)
+      {
+        if (!(dt >= 0.0f) || !(ctx->omegamax[c] * dt < 6.0f))
+          return false;
+      }
+    }
+
+    return true;
   }
 
   // flush queued updates that do not fit into one displace call
@@ -176,6 +204,17 @@ namespace
       int n = (int)std::min<size_t>(MAX_PENDING, ctx->pending.size() - keep);
 
       StepArgs a = make_args(ctx, n, ctx->pending.data());
+
+      // fmod keeps the sign of its first operand: a negative dt can leave phases below zero, which the
+      // fused fast path must never see
+      for(int i = 0; i < n; ++i)
+      {
+        if (!(ctx->pending[i] >= 0.0f))
+        {
+          for(int c = 0; c < ctx->cascades; ++c)
+            ctx->wildphase[c] = true;
+        }
+      }
 
       dim3 grid(1024, ctx->cascades);
       hipLaunchKernelGGL(ocean_advance_kernel, grid, dim3(256), 0, ctx->stream, a, ctx->N);
@@ -423,10 +462,19 @@ int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, fl
 
   HIPCHECK(ctx, hipMemcpyAsync(ctx->h0 + cascade * P, h0, P * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
 
+  bool wild = false;
+
   if (phase)
+  {
+    for(size_t i = 0; i < P && !wild; ++i)
+      wild = !(phase[i] >= 0.0f && phase[i] < 6.2831855f);
+
     HIPCHECK(ctx, hipMemcpyAsync(ctx->phase + cascade * P, phase, P * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  }
   else
     HIPCHECK(ctx, hipMemsetAsync(ctx->phase + cascade * P, 0, P * sizeof(float), ctx->stream));
+
+  ctx->wildphase[cascade] = wild;
 
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));   // the host buffers are the caller's again
 
@@ -484,9 +532,16 @@ int datum_ocean_displace(datum_ocean_t ctx)
 
   HIPCHECK(ctx, hipSetDevice(ctx->device));
 
-  int rc = flush_pending(ctx, MAX_PENDING);
-  if (rc == DATUM_OCEAN_OK && !ctx->pending.empty())
+  int rc = DATUM_OCEAN_OK;
+
+  if (!ctx->pending.empty())
+  {
     rc = ensure_omega(ctx);
+
+    if (rc == DATUM_OCEAN_OK)
+      rc = flush_pending(ctx, fusable(ctx) ? MAX_PENDING : 0);
+  }
+
   if (rc != DATUM_OCEAN_OK)
     return rc;
 

@@ -101,20 +101,22 @@ namespace ocean
     return table[i * (N / 2 + 1) + j];
   }
 
-  // fmod(phase + w*dt, 2 pi) of ocean.cpp:231.  fmod is exact; for 2pi <= a < 4pi it is a - 2pi (exact, Sterbenz)
+  // fmod(phase + w*dt, 2 pi) of ocean.cpp:231, any operands (phase-only kernel).  fmod is exact.
   __device__ __forceinline__ float advance_phase(float phase, float wdt)
+  {
+    return fmodf(phase + wdt, 6.2831855f);
+  }
+
+  // the same for 0 <= phase < 2 pi and 0 <= w*dt < 2 pi, which is what the fused row pass is given (the host
+  // checks both and otherwise runs the phase-only kernel first): then 0 <= a < 4 pi and fmod(a, 2 pi) is a or
+  // a - 2 pi, the subtraction being exact (Sterbenz), so the result is bit-identical to fmod's
+  __device__ __forceinline__ float advance_phase_fast(float phase, float wdt)
   {
     const float twopi = 6.2831855f;
 
     float a = phase + wdt;
 
-    if (a >= 0.0f && a < twopi)
-      return a;
-
-    if (a >= twopi && a < 2.0f * twopi)
-      return a - twopi;
-
-    return fmodf(a, twopi);
+    return (a >= twopi) ? a - twopi : a;
   }
 
   //|---------------------- ocean.sim -----------------------------------------
@@ -177,6 +179,20 @@ namespace ocean
     float inv = kinv_of(kx, ky);
 
     return make_float2(kx * inv, ky * inv);
+  }
+
+  // timing-only ablations (never defined in a shipped build): -DOCEAN_ABLATE_ROWLOAD / ROWSTORE / ROWFFT /
+  // COLLOAD / COLSTORE / COLFFT remove one ingredient while keeping the rest alive
+#if defined(OCEAN_ABLATE_ROWSTORE) || defined(OCEAN_ABLATE_COLSTORE)
+  #define OCEAN_ABLATION 1
+#endif
+
+  // pins program order for the compiler (memory operations) and for the machine scheduler (everything):
+  // used around software prefetches so that requests are issued where they are written
+  __device__ __forceinline__ void order_fence()
+  {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   //|---------------------- line FFTs with workgroup barriers ------------------
@@ -260,6 +276,9 @@ namespace ocean
 #ifndef OCEAN_ROW_FIELDS
 #define OCEAN_ROW_FIELDS 3          // fields per barrier phase: 1 or 3
 #endif
+#ifndef OCEAN_ROW_GROUPS
+#define OCEAN_ROW_GROUPS 1          // row groups a workgroup processes back to back (input prefetch depth 1)
+#endif
 #ifndef OCEAN_COL_THREADS
 #define OCEAN_COL_THREADS 512
 #endif
@@ -274,20 +293,21 @@ namespace ocean
     static constexpr int K = OCEAN_ROW_FIELDS;
     static constexpr int ROWS = (OCEAN_ROW_THREADS / T) < 1 ? 1 : (OCEAN_ROW_THREADS / T) > 8 ? 8 : (OCEAN_ROW_THREADS / T);
     static constexpr int THREADS = ROWS * T;
-    static constexpr int GROUPS = N / ROWS;                                            // workgroups per cascade
+    static constexpr int GPW = (N / ROWS) % (16 * OCEAN_ROW_GROUPS) == 0 ? OCEAN_ROW_GROUPS : 1;    // row groups per workgroup, one after the other
+    static constexpr int BLOCKS = N / (ROWS * GPW);                                    // workgroups per cascade
     static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_ROW_MINWAVES : 1;        // per SIMD
     static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)ROWS * K * Plan<N>::LINE) * sizeof(cf);
 
     static_assert(K == 1 || K == 3, "OCEAN_ROW_FIELDS must be 1 or 3");
   };
 
-  // Which row group a workgroup takes.  Blocks are dealt round-robin over the 8 XCDs (blockIdx.x % 8, speed
-  // only): each XCD gets a band of row groups together with the mirrored band, because row y reads h0 of row
+  // Which band of rows a workgroup takes.  Blocks are dealt round-robin over the 8 XCDs (blockIdx.x % 8, speed
+  // only): each XCD gets a set of bands together with the mirrored bands, because row y reads h0 of row
   // N-1-y (sim.comp:59) and the dispersion row |y - N/2|, so both come out of that XCD's L2 the second time.
   template<int N>
-  __device__ __forceinline__ int rowgroup_of_block(int b)
+  __device__ __forceinline__ int rowband_of_block(int b)
   {
-    constexpr int G = RowCfg<N>::GROUPS;
+    constexpr int G = RowCfg<N>::BLOCKS;
 
     if (G % 16 != 0)
       return b;
@@ -297,6 +317,51 @@ namespace ocean
     int pair = xcd * (G / 16) + (slot >> 1);
 
     return (slot & 1) ? (G - 1 - pair) : pair;
+  }
+
+  // inputs of ocean.sim for one row segment: this row of h0 and phase, the -k partner row read backwards
+  // (sim.comp:59: index (N-1-y, N-1-x)) and the dispersion (only when an update is pending)
+  template<int N>
+  struct SimInputs
+  {
+    float ph[Plan<N>::E];
+    float om[Plan<N>::E];
+    float2 hk[Plan<N>::E];
+    float2 hm[Plan<N>::E];
+  };
+
+  template<int N>
+  __device__ __forceinline__ void load_sim_inputs(SimInputs<N> &in, float2 const *h0, float const *phase, float const *omega, int y, int t, bool advance)
+  {
+    constexpr int E = Plan<N>::E;
+    constexpr int T = Plan<N>::T;
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+    {
+      int x = t + T * s;
+
+#ifdef OCEAN_ABLATE_ROWLOAD
+      in.ph[s] = 0.001f * (float)x;
+      in.hk[s] = make_float2(0.01f * (float)(x & 15), 0.02f);
+      in.hm[s] = make_float2(0.03f, 0.01f * (float)(y & 15));
+#else
+      in.ph[s] = phase[(size_t)y * N + x];
+      in.hk[s] = h0[(size_t)y * N + x];
+      in.hm[s] = h0[(size_t)(N - 1 - y) * N + (N - 1 - x)];
+#endif
+    }
+
+    if (advance)
+    {
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+#ifdef OCEAN_ABLATE_ROWLOAD
+        in.om[s] = 1.0f + 0.001f * (float)s;
+#else
+        in.om[s] = dispersion_lookup(omega, t + T * s, y, N);
+#endif
+    }
   }
 
   template<int N>
@@ -315,7 +380,7 @@ namespace ocean
     int const cascade = blockIdx.y;
     int const r = threadIdx.x / T;
     int const t = threadIdx.x % T;
-    int const y = rowgroup_of_block<N>(blockIdx.x) * C::ROWS + r;
+    int const y0 = rowband_of_block<N>(blockIdx.x) * (C::ROWS * C::GPW) + r;
 
     cf *midtab = reinterpret_cast<cf*>(smem);
     cf *line = midtab + L::MIDTAB + r * K * P::LINE;
@@ -332,130 +397,173 @@ namespace ocean
     cf *spec = a.spec + cascade * 3 * plane;
     float const *omega = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
 
-    float const ky = wavevector(y, N, cc.scale);
-
-    // ocean.sim for this row: this row of h0 and phase, and the -k partner row read backwards
-    // (sim.comp:59: index (N-1-y, N-1-x)).  update_ocean (ocean.cpp:223-233) is applied on the way,
-    // each pending dt in turn.
-    cf h[E];
-    float kinv[E];
-
-    {
-      float ph[E], om[E];
-      float2 hk[E], hm[E];
-
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-      {
-        int x = t + T * s;
-
-        ph[s] = phase[(size_t)y * N + x];
-        hk[s] = h0[(size_t)y * N + x];
-        hm[s] = h0[(size_t)(N - 1 - y) * N + (N - 1 - x)];
-      }
-
-      if (a.ndt > 0)
-      {
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-          om[s] = dispersion_lookup(omega, t + T * s, y, N);
-
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-        {
-          float p = ph[s];
-          for(int k = 0; k < a.ndt; ++k)
-            p = advance_phase(p, om[s] * a.dt[k]);
-
-          ph[s] = p;
-          phase[(size_t)y * N + t + T * s] = p;
-        }
-      }
-
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-      {
-        h[s] = sim_height(hk[s], hm[s], ph[s]);
-        kinv[s] = kinv_of(wavevector(t + T * s, N, cc.scale), ky);
-      }
-    }
+    bool const advance = a.ndt > 0;
 
     typename L::Twiddles w;
     L::load_twiddles(a.tw, t, w);
 
-    // hx = -i h k^x, hy = -i h k^y (sim.comp:68-74) and h itself, each through the row transform
-    if (K == 3)
+    // GPW row groups one after the other.  The inputs of group g + 1 are requested right after group g's
+    // ocean.sim, so their latency is covered by group g's butterflies and barriers; the compiler barriers pin
+    // that order (requests neither sink below the transforms nor pile up at the top of the kernel).
+    SimInputs<N> in;
+
+    load_sim_inputs<N>(in, h0, phase, omega, y0, t, advance);
+
+    order_fence();
+
+    #pragma unroll 1
+    for(int g = 0; g < C::GPW; ++g)
     {
-      cf v[K][E];
+      int const y = y0 + g * C::ROWS;
 
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
+      float const ky = wavevector(y, N, cc.scale);
+
+      // update_ocean (ocean.cpp:223-233), each pending dt in turn, then ocean.sim
+      cf h[E];
+      float kinv[E];
+
+      if (advance)
       {
-        float kx = wavevector(t + T * s, N, cc.scale) * kinv[s];
-        float kyn = ky * kinv[s];
+        for(int k = 0; k < a.ndt; ++k)
+        {
+          float const dt = a.dt[k];
 
-        v[0][s] = h[s];
-        v[1 % K][s] = cf{ h[s].y * kx, -h[s].x * kx };
-        v[2 % K][s] = cf{ h[s].y * kyn, -h[s].x * kyn };
-      }
-
-      fft_lines<N, K>(v, t, line, P::LINE, midtab, w, true);
-
-      #pragma unroll
-      for(int field = 0; field < K; ++field)
-      {
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-          spec[field * plane + blocked<N>(y, t + T * s)] = v[field][s];
-      }
-    }
-    else
-    {
-      #pragma unroll
-      for(int field = 2; field >= 0; --field)
-      {
-        cf v[1][E];
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+            in.ph[s] = advance_phase_fast(in.ph[s], in.om[s] * dt);
+        }
 
         #pragma unroll
         for(int s = 0; s < E; ++s)
         {
-          float kc = ((field == 1) ? wavevector(t + T * s, N, cc.scale) : ky) * kinv[s];
-
-          v[0][s] = (field == 0) ? h[s] : cf{ h[s].y * kc, -h[s].x * kc };
+#ifdef OCEAN_ABLATE_ROWSTORE
+          if (in.ph[s] == 123456.789f)
+#endif
+          phase[(size_t)y * N + t + T * s] = in.ph[s];
         }
+      }
 
-        fft_lines<N, 1>(v, t, line, P::LINE, midtab, w, true);
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+        h[s] = sim_height(in.hk[s], in.hm[s], in.ph[s]);
+        kinv[s] = kinv_of(wavevector(t + T * s, N, cc.scale), ky);
+      }
+
+      order_fence();
+
+      if (g + 1 < C::GPW)
+        load_sim_inputs<N>(in, h0, phase, omega, y + C::ROWS, t, advance);
+
+      order_fence();
+
+      // hx = -i h k^x, hy = -i h k^y (sim.comp:68-74) and h itself, each through the row transform
+      if (K == 3)
+      {
+        cf v[K][E];
 
         #pragma unroll
         for(int s = 0; s < E; ++s)
-          spec[field * plane + blocked<N>(y, t + T * s)] = v[0][s];
+        {
+          float kx = wavevector(t + T * s, N, cc.scale) * kinv[s];
+          float kyn = ky * kinv[s];
+
+          v[0][s] = h[s];
+          v[1 % K][s] = cf{ h[s].y * kx, -h[s].x * kx };
+          v[2 % K][s] = cf{ h[s].y * kyn, -h[s].x * kyn };
+        }
+
+#ifndef OCEAN_ABLATE_ROWFFT
+        fft_lines<N, K>(v, t, line, P::LINE, midtab, w, true);
+#endif
+
+        #pragma unroll
+        for(int field = 0; field < K; ++field)
+        {
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+          {
+#ifdef OCEAN_ABLATE_ROWSTORE
+            if (v[field][s].x == 123456.789f)
+#endif
+            spec[field * plane + blocked<N>(y, t + T * s)] = v[field][s];
+          }
+        }
       }
+      else
+      {
+        #pragma unroll
+        for(int field = 2; field >= 0; --field)
+        {
+          cf v[1][E];
+
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+          {
+            float kc = ((field == 1) ? wavevector(t + T * s, N, cc.scale) : ky) * kinv[s];
+
+            v[0][s] = (field == 0) ? h[s] : cf{ h[s].y * kc, -h[s].x * kc };
+          }
+
+          fft_lines<N, 1>(v, t, line, P::LINE, midtab, w, true);
+
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+            spec[field * plane + blocked<N>(y, t + T * s)] = v[0][s];
+        }
+      }
+
+      order_fence();
     }
   }
 
   //|---------------------- column pass + map ---------------------------------
 
+#ifndef OCEAN_COL_CPT
+#define OCEAN_COL_CPT 2             // adjacent columns per thread: 2 (16-byte accesses) or 1
+#endif
+
   template<int N>
   struct ColCfg
   {
     static constexpr int T = Plan<N>::T;
-    static constexpr int WC = (OCEAN_COL_THREADS / T) < 1 ? 1 : (OCEAN_COL_THREADS / T) > 8 ? 8 : (OCEAN_COL_THREADS / T);   // column pairs in flight
-    static constexpr int W = 2 * WC;                                    // tile width: two adjacent columns per thread
+    static constexpr int CPT = OCEAN_COL_CPT;
+    static constexpr int WC = (OCEAN_COL_THREADS / T) < 1 ? 1 : (OCEAN_COL_THREADS / T) > 8 ? 8 : (OCEAN_COL_THREADS / T);   // threads across a tile row
+    static constexpr int W = CPT * WC;                                  // tile width in columns
     static constexpr int THREADS = WC * T;
     static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_COL_MINWAVES : 1;
     static constexpr int CS = Plan<N>::LINE + 2;                        // LDS line stride (complex), == 2 mod 16
     static constexpr int SY = N + 4;                                    // height exchange: column stride (floats)
+    static constexpr int HR = (2 + WC - 1) / WC;                        // halo rounds (1 unless WC == 1)
 
-    // LDS carve, in bytes: first middle-pass twiddles | heights of the two halo columns | 2 WC transform lines
-    // (both columns of every pair are in flight), later reused for the heights of the tile's own columns
+    // LDS carve, in bytes: first middle-pass twiddles | heights of the two halo columns | W transform lines
+    // (every column of the tile is in flight), later reused for the heights of the tile's own columns
     static constexpr size_t OFF_HALO = (size_t)LineFFT<N>::MIDTAB * sizeof(cf);
     static constexpr size_t OFF_MAIN = OFF_HALO + (size_t)2 * SY * sizeof(float);
-    static constexpr size_t MAIN_FFT = (size_t)2 * WC * CS * sizeof(cf);
+    static constexpr size_t MAIN_FFT = (size_t)(W > 2 ? W : 2) * CS * sizeof(cf);
     static constexpr size_t MAIN_DZ = (size_t)W * SY * sizeof(float);
     static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
 
-    static_assert(N % W == 0 && W % 2 == 0, "bad tile width");
+    static_assert(CPT == 1 || CPT == 2, "OCEAN_COL_CPT must be 1 or 2");
+    static_assert(N % W == 0, "bad tile width");
     static_assert(OFF_MAIN % 16 == 0, "LDS carve must stay 16-byte aligned");
+  };
+
+  // CPT adjacent spectrum values of one row: one 8- or 16-byte load
+  template<int CPT> struct SpecLoad;
+
+  template<> struct SpecLoad<1>
+  {
+    cf v;
+    __device__ __forceinline__ void load(cf const *p) { v = *p; }
+    __device__ __forceinline__ cf get(int) const { return v; }
+  };
+
+  template<> struct SpecLoad<2>
+  {
+    float4 v;
+    __device__ __forceinline__ void load(cf const *p) { v = *reinterpret_cast<float4 const*>(p); }
+    __device__ __forceinline__ cf get(int i) const { return i == 0 ? cf{ v.x, v.y } : cf{ v.z, v.w }; }
   };
 
   template<int N>
@@ -469,12 +577,14 @@ namespace ocean
     constexpr int T = P::T;
     constexpr int W = C::W;
     constexpr int WC = C::WC;
+    constexpr int CPT = C::CPT;
+    constexpr int HR = C::HR;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     cf *midtab = reinterpret_cast<cf*>(smem);
     float *dzhalo = reinterpret_cast<float*>(smem + C::OFF_HALO);     // [2][SY]: columns x0 - 1 and x0 + W
-    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [2 WC][CS]
+    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [W][CS]
     float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [W][SY], after the transforms
 
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
@@ -491,31 +601,69 @@ namespace ocean
     float4 *layer0 = a.maps + (size_t)cascade * 2 * plane;
     float4 *layer1 = layer0 + plane;
 
-    // halo round first (nothing else is live yet): height of the two columns bordering the tile
-    // (periodic, map.comp:58).  Line slot hc = thread / T (2 WC >= 2 of them), row group ht = thread % T.
-    {
-      int const hc = threadIdx.x / T;
-      int const ht = threadIdx.x % T;
+    // thread roles.  halo rounds: line slot hc = thread / T, row group ht = thread % T.
+    // main rounds: column group cp (fastest over lanes) = columns xa .. xa + CPT - 1; row group t.
+    int const hc = threadIdx.x / T;
+    int const ht = threadIdx.x % T;
 
+    int const cp = threadIdx.x % WC;
+    int const t = threadIdx.x / WC;
+    int const xa = x0 + CPT * cp;
+
+    // all requests for the first two rounds go out before any transform: the halo columns (height only) and
+    // field 0; later every field is requested one round ahead of its use
+    cf vh[HR][E];
+
+    #pragma unroll
+    for(int hr = 0; hr < HR; ++hr)
+    {
+      int const side = hr * WC + hc;
+      int const hx = (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
+
+      if (side < 2)
+      {
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+        {
+#ifdef OCEAN_ABLATE_COLLOAD
+          vh[hr][s] = cf{ 0.01f * (float)(ht & 31), 0.02f * (float)s };
+#else
+          vh[hr][s] = spec[blocked<N>(ht + T * s, hx)];
+#endif
+        }
+      }
+    }
+
+    SpecLoad<CPT> q[2][E];
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+    {
+#ifdef OCEAN_ABLATE_COLLOAD
+      q[0][s].load(midtab + ((t + s + cp) & 31));
+#else
+      q[0][s].load(spec + blocked<N>(t + T * s, xa));
+#endif
+    }
+
+    // halo rounds: height of the two columns bordering the tile (periodic, map.comp:58)
+    {
       typename L::Twiddles hw;
       L::load_twiddles(a.tw, ht, hw);
 
       #pragma unroll
-      for(int first = 0; first < 2; first += WC)
+      for(int hr = 0; hr < HR; ++hr)
       {
-        int const side = first + hc;
+        int const side = hr * WC + hc;
         bool const halo = side < 2;
         int const hx = (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
         float const hsigma = ((hx + ht) & 1) ? -1.0f : 1.0f;
 
         cf v[1][E];
 
-        if (halo)
-        {
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-            v[0][s] = spec[blocked<N>(ht + T * s, hx)];
-        }
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+          v[0][s] = vh[hr][s];
 
         fft_lines<N, 1>(v, ht, lines + hc * C::CS, C::CS, midtab, hw, halo);
 
@@ -528,63 +676,79 @@ namespace ocean
       }
     }
 
-    // main rounds: column pair cp (fastest over lanes) = columns xa, xa + 1; row group t
-    int const cp = threadIdx.x % WC;
-    int const t = threadIdx.x / WC;
-    int const xa = x0 + 2 * cp;
-
     typename L::Twiddles w;
     L::load_twiddles(a.tw, t, w);
 
-    // (-1)^(x+y) of map.comp:60; y = t + T s with T even and xa even: fixed per thread, opposite for xa + 1
-    float const sigma = (t & 1) ? -1.0f : 1.0f;
+    // (-1)^(x+y) of map.comp:60; y = t + T s with T even: fixed per thread and column, alternating over columns
+    float sig[CPT];
 
-    float dxa[E], dya[E], dza[E];
-    float dxb[E], dyb[E], dzb[E];
+    #pragma unroll
+    for(int c = 0; c < CPT; ++c)
+      sig[c] = ((xa + c + t) & 1) ? -1.0f : 1.0f;
+
+    float dx[CPT][E], dy[CPT][E], dz[CPT][E];
 
     // height, then choppy x / y displacement: Re(column transform) * sigma [* choppiness] (map.comp:62-64)
     #pragma unroll
     for(int field = 0; field < 3; ++field)
     {
-      cf v[2][E];
-
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
+      if (field + 1 < 3)
       {
-        float4 q = *reinterpret_cast<float4 const*>(spec + field * plane + blocked<N>(t + T * s, xa));
-
-        v[0][s] = cf{ q.x, q.y };
-        v[1][s] = cf{ q.z, q.w };
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+        {
+#ifdef OCEAN_ABLATE_COLLOAD
+          q[(field + 1) & 1][s].load(midtab + ((t + s + cp + field) & 31));
+#else
+          q[(field + 1) & 1][s].load(spec + (field + 1) * plane + blocked<N>(t + T * s, xa));
+#endif
+        }
       }
 
-      fft_lines<N, 2>(v, t, lines + 2 * cp * C::CS, C::CS, midtab, w, true);
+      cf v[CPT][E];
 
       #pragma unroll
-      for(int s = 0; s < E; ++s)
+      for(int c = 0; c < CPT; ++c)
       {
-        if (field == 0) { dza[s] = v[0][s].x * sigma; dzb[s] = v[1][s].x * -sigma; }
-        if (field == 1) { dxa[s] = v[0][s].x * sigma * cc.choppiness; dxb[s] = v[1][s].x * -sigma * cc.choppiness; }
-        if (field == 2) { dya[s] = v[0][s].x * sigma * cc.choppiness; dyb[s] = v[1][s].x * -sigma * cc.choppiness; }
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+          v[c][s] = q[field & 1][s].get(c);
+      }
+
+#ifndef OCEAN_ABLATE_COLFFT
+      fft_lines<N, CPT>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
+#endif
+
+      #pragma unroll
+      for(int c = 0; c < CPT; ++c)
+      {
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+        {
+          if (field == 0) dz[c][s] = v[c][s].x * sig[c];
+          if (field == 1) dx[c][s] = v[c][s].x * sig[c] * cc.choppiness;
+          if (field == 2) dy[c][s] = v[c][s].x * sig[c] * cc.choppiness;
+        }
       }
     }
 
     // exchange heights (the transform lines are free after the last barrier of fft_lines)
-    float *owna = dzmain + (2 * cp) * C::SY;
-    float *ownb = owna + C::SY;
+    float *own = dzmain + (CPT * cp) * C::SY;
 
     #pragma unroll
-    for(int s = 0; s < E; ++s)
+    for(int c = 0; c < CPT; ++c)
     {
-      owna[t + T * s] = dza[s];
-      ownb[t + T * s] = dzb[s];
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+        own[c * C::SY + t + T * s] = dz[c][s];
     }
 
     __syncthreads();
 
-    float const *left = (cp == 0) ? dzhalo : owna - C::SY;
-    float const *right = (cp == WC - 1) ? dzhalo + C::SY : ownb + C::SY;
+    float const *left = (cp == 0) ? dzhalo : own - C::SY;
+    float const *right = (cp == WC - 1) ? dzhalo + C::SY : own + CPT * C::SY;
 
-    // central-difference normal (map.comp:72-77) and the two image stores (map.comp:79-80), two texels per row
+    // central-difference normal (map.comp:72-77) and the two image stores (map.comp:79-80)
     #pragma unroll
     for(int s = 0; s < E; ++s)
     {
@@ -594,20 +758,26 @@ namespace ocean
 
       float nz = cc.nz;
 
-      float nxa = left[y] - dzb[s];
-      float nya = owna[yd] - owna[yu];
-      float inva = rsqrtf(nxa * nxa + nya * nya + nz * nz);
-
-      float nxb = dza[s] - right[y];
-      float nyb = ownb[yd] - ownb[yu];
-      float invb = rsqrtf(nxb * nxb + nyb * nyb + nz * nz);
-
       size_t o = (size_t)y * N + xa;
 
-      layer0[o] = make_float4(dxa[s], dya[s], dza[s], 0.0f);
-      layer0[o + 1] = make_float4(dxb[s], dyb[s], dzb[s], 0.0f);
-      layer1[o] = make_float4(nxa * inva, nya * inva, nz * inva, 0.0f);
-      layer1[o + 1] = make_float4(nxb * invb, nyb * invb, nz * invb, 0.0f);
+      #pragma unroll
+      for(int c = 0; c < CPT; ++c)
+      {
+        float l = (c == 0) ? left[y] : dz[c > 0 ? c - 1 : 0][s];
+        float r = (c == CPT - 1) ? right[y] : dz[c + 1 < CPT ? c + 1 : 0][s];
+
+        float nx = l - r;
+        float ny = own[c * C::SY + yd] - own[c * C::SY + yu];
+        float inv = rsqrtf(nx * nx + ny * ny + nz * nz);
+
+#ifdef OCEAN_ABLATE_COLSTORE
+        if (nx * inv + dx[c][s] + dy[c][s] == 123456.789f)
+#endif
+        {
+          layer0[o + c] = make_float4(dx[c][s], dy[c][s], dz[c][s], 0.0f);
+          layer1[o + c] = make_float4(nx * inv, ny * inv, nz * inv, 0.0f);
+        }
+      }
     }
   }
 

@@ -105,6 +105,44 @@ def test_phase_is_bit_exact(capi, oracle, N):
     assert np.array_equal(got, want)
 
 
+def test_phase_out_of_range_inputs(capi, oracle):
+    # phases outside [0, 2 pi) (uploaded by the caller, or produced by a negative dt) and time steps too large for
+    # the fused fast path must take the general fmod route and still match update_ocean bit for bit
+    N = 256
+    p = oracle.EXAMPLE
+    h0 = make_state(oracle, N, 1000)
+    rng = np.random.default_rng(1)
+    phase0 = ((rng.random((N, N)) - 0.3) * 40).astype(np.float32)  # negative and > 2 pi values
+    dts = [DT, np.float32(-0.25), DT, np.float32(50.0), DT, DT]
+    want = phase0.copy()
+    for dt in dts:
+        oracle.update(want, p["wavescale"], dt)
+    with capi.Ocean(N, 1) as oc:
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        oc.upload_state(0, h0, phase0)
+        for dt in dts[:3]:
+            oc.update(dt)
+        oc.displace()
+        for dt in dts[3:]:
+            oc.update(dt)
+            oc.displace()
+        got = oc.read_state(0)
+        maps = oc.read_maps(0)
+    assert np.array_equal(got, want)
+    ref = oracle.displace(h0, want.copy(), p["wavescale"], p["choppiness"], w=oracle.weights(N, reduced=True))
+    assert rmse(maps[..., :3], ref[..., :3]) < 1e-5
+    # a state that starts in range and only ever sees a negative dt afterwards
+    with capi.Ocean(N, 1) as oc:
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        oc.upload_state(0, h0)
+        want = np.zeros((N, N), np.float32)
+        for dt in (DT, np.float32(-0.1), DT, DT):
+            oc.update(dt)
+            oc.displace()
+            oracle.update(want, p["wavescale"], dt)
+        assert np.array_equal(oc.read_state(0), want)
+
+
 @pytest.mark.parametrize("N", [64, 256, 1024])
 def test_sim_stage(capi, oracle, N):
     p = oracle.EXAMPLE

@@ -5,7 +5,7 @@ set -u
 out=gpurun_out/$1; shift
 mkdir -p $out
 export TMPDIR=/tmp
-ARGS="--steps 30 --warmup 5 --cpu-seconds 0 $*"
+ARGS="--cpu-seconds 0 $*"   # bench.py defaults (200 steps, 10 warm-up, 1024x1024 x 4) without the CPU leg
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $ARGS > $out/trace.log 2>&1
 i=0
 for pmc in \
