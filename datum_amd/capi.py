@@ -71,7 +71,7 @@ SYMBOLS = {
     "datum_ocean_reference_weights": (I, [I, P]),
     "datum_ocean_debug_sim": (I, [P, I, P, P, P]),
     "datum_ocean_debug_rowpass": (I, [P, I, P, P, P]),
-    "datum_ocean_profile_begin": (I, [P, I]),
+    "datum_ocean_profile_begin": (I, [P, I, I]),
     "datum_ocean_profile_end": (I, [P, ctypes.POINTER(D), ctypes.POINTER(D), ctypes.POINTER(I)]),
     "datum_ocean_algorithmic_bytes": (I, [P, ctypes.POINTER(D), ctypes.POINTER(D)]),
 }
@@ -210,8 +210,8 @@ class Ocean:
         self._check(self.lib.datum_ocean_debug_rowpass(self.h, cascade, _ptr(h), _ptr(hx), _ptr(hy)))
         return h, hx, hy
 
-    def profile_begin(self, max_steps):
-        self._check(self.lib.datum_ocean_profile_begin(self.h, max_steps))
+    def profile_begin(self, max_samples, stride=1):
+        self._check(self.lib.datum_ocean_profile_begin(self.h, max_samples, stride))
 
     def profile_end(self):
         row, col, n = D(), D(), I()

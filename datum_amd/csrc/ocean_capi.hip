@@ -28,6 +28,7 @@ struct datum_ocean_ctx
   float2 *h0 = nullptr;
   float *phase = nullptr;
   cf *spec = nullptr;
+  cf *halo = nullptr;                 // [cascade][tiles][2][N] tile-border columns of the row-transformed height
   float4 *maps = nullptr;             // the one in use
   float4 *ownmaps = nullptr;
   cf *tw = nullptr;
@@ -49,6 +50,8 @@ struct datum_ocean_ctx
   bool profiling = false;
   int profmax = 0;
   int profsteps = 0;
+  int profstride = 1;
+  long profcalls = 0;
   std::vector<hipEvent_t> events;     // 3 per step
 
   std::string error;
@@ -89,6 +92,7 @@ namespace
     a.h0 = ctx->h0;
     a.phase = ctx->phase;
     a.spec = ctx->spec;
+    a.halo = ctx->halo;
     a.maps = ctx->maps;
     a.tw = ctx->tw;
     a.omega = ctx->omega;
@@ -272,6 +276,11 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
   CREATECHECK(hipMalloc(&ctx->phase, cascades * P * sizeof(float)));
   CREATECHECK(hipMalloc(&ctx->spec, cascades * 3 * P * sizeof(cf)));
   CREATECHECK(hipMalloc(&ctx->ownmaps, cascades * 2 * P * sizeof(float4)));
+  {
+    size_t tiles = 0;
+    DISPATCH_N(resolution, tiles = TileCfg<NN>::TILES);
+    CREATECHECK(hipMalloc(&ctx->halo, (size_t)cascades * tiles * 2 * resolution * sizeof(cf)));
+  }
   CREATECHECK(hipMalloc(&ctx->tw, resolution * sizeof(cf)));
   CREATECHECK(hipMalloc(&ctx->omega, (size_t)cascades * (resolution / 2 + 1) * (resolution / 2 + 1) * sizeof(float)));
   CREATECHECK(hipMalloc(&ctx->wavescales, DATUM_OCEAN_MAX_CASCADES * sizeof(float)));
@@ -348,6 +357,7 @@ int datum_ocean_destroy(datum_ocean_t ctx)
   (void)hipFree(ctx->h0);
   (void)hipFree(ctx->phase);
   (void)hipFree(ctx->spec);
+  (void)hipFree(ctx->halo);
   (void)hipFree(ctx->ownmaps);
   (void)hipFree(ctx->tw);
   (void)hipFree(ctx->omega);
@@ -548,7 +558,7 @@ int datum_ocean_displace(datum_ocean_t ctx)
   StepArgs a = make_args(ctx, (int)ctx->pending.size(), ctx->pending.data());
   ctx->pending.clear();
 
-  bool const prof = ctx->profiling && ctx->profsteps < ctx->profmax;
+  bool const prof = ctx->profiling && ctx->profsteps < ctx->profmax && (ctx->profcalls++ % ctx->profstride) == 0;
   hipEvent_t *ev = prof ? &ctx->events[3 * ctx->profsteps] : nullptr;
 
   if (prof)
@@ -805,9 +815,9 @@ int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *h, float *h
   return DATUM_OCEAN_OK;
 }
 
-int datum_ocean_profile_begin(datum_ocean_t ctx, int max_steps)
+int datum_ocean_profile_begin(datum_ocean_t ctx, int max_steps, int stride)
 {
-  if (!ctx || max_steps < 1)
+  if (!ctx || max_steps < 1 || stride < 1)
     return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_profile_begin: bad argument");
 
   HIPCHECK(ctx, hipSetDevice(ctx->device));
@@ -822,6 +832,8 @@ int datum_ocean_profile_begin(datum_ocean_t ctx, int max_steps)
   ctx->profiling = true;
   ctx->profmax = max_steps;
   ctx->profsteps = 0;
+  ctx->profstride = stride;
+  ctx->profcalls = 0;
 
   return DATUM_OCEAN_OK;
 }

@@ -55,7 +55,10 @@ namespace ocean
   {
     static_assert(N == 64 || N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096, "unsupported resolution");
 
-    static constexpr int E = (N == 64) ? 4 : 8;
+#ifndef OCEAN_FFT_E
+#define OCEAN_FFT_E 8
+#endif
+    static constexpr int E = (N == 64) ? 4 : OCEAN_FFT_E;
     static constexpr int T = N / E;
     static constexpr int NP = plan_passes(N, E);
     static constexpr int RL = N / ipow(E, NP - 1);
@@ -63,7 +66,7 @@ namespace ocean
     static constexpr int NS_LAST = N / RL;      // product of the radices before the last pass
     static constexpr int LINE = N + N / 16;     // padded LDS line length, in complex elements
 
-    static_assert(NP >= 2 && NP <= 4, "bad plan");
+    static_assert(NP >= 2 && NP <= 6, "bad plan");
     static_assert(RL >= 2 && RL <= E && E % RL == 0, "bad plan");
     static_assert(ipow(E, NP - 1) * RL == N, "bad plan");
   };
@@ -278,8 +281,10 @@ namespace ocean
       }
       else
       {
+        constexpr int MI = (PASS >= 2 && PASS - 2 < NMIDREG) ? PASS - 2 : 0;
+
         cf p[E];
-        twiddle_powers<E>(w.mid[PASS >= 2 ? PASS - 2 : 0], p);
+        twiddle_powers<E>(w.mid[MI], p);
 
         OC_UNROLL
         for(int r = 1; r < E; ++r)

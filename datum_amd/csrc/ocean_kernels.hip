@@ -45,10 +45,20 @@ namespace ocean
     float4 *maps;        // [cascade][2][N*N]    displacementmap, 2 layers RGBA32F
     cf const *tw;        // [N]                  exp(+2 pi i k / N)
     float const *omega;  // [cascade][(N/2+1)^2] dispersion(k) by (|m - N/2|, |n - N/2|)
+    cf *halo;            // [cascade][N/W tiles][2 sides][N] row-transformed h of the columns bordering each tile
     int ndt;
     float dt[MAX_PENDING];
     CascadeConst casc[DATUM_OCEAN_MAX_CASCADES];
+#ifdef OCEAN_STAMPS
+    unsigned long long *stamps;   // diagnostic builds only (tools/dbg/stamps.hip): [kernel][workgroup][16] s_memtime values
+#endif
   };
+
+#ifdef OCEAN_STAMPS
+  #define OCEAN_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) stampbase[slot] = t_; } while(0)
+#else
+  #define OCEAN_STAMP(slot) do { } while(0)
+#endif
 
   template<int N>
   __host__ __device__ __forceinline__ size_t blocked(int y, int x)
@@ -255,6 +265,48 @@ namespace ocean
       __syncthreads();
     }
 
+    if (Plan<N>::NP >= 5)
+    {
+      if (active)
+      {
+        #pragma unroll
+        for(int k = 0; k < K; ++k)
+          L::template mid_load<3>(v[k], t, line + k * linestride, midtab, w);
+      }
+
+      __syncthreads();
+
+      if (active)
+      {
+        #pragma unroll
+        for(int k = 0; k < K; ++k)
+          L::template mid_store<3>(v[k], t, line + k * linestride);
+      }
+
+      __syncthreads();
+    }
+
+    if (Plan<N>::NP >= 6)
+    {
+      if (active)
+      {
+        #pragma unroll
+        for(int k = 0; k < K; ++k)
+          L::template mid_load<4>(v[k], t, line + k * linestride, midtab, w);
+      }
+
+      __syncthreads();
+
+      if (active)
+      {
+        #pragma unroll
+        for(int k = 0; k < K; ++k)
+          L::template mid_store<4>(v[k], t, line + k * linestride);
+      }
+
+      __syncthreads();
+    }
+
     if (active)
     {
       #pragma unroll
@@ -264,6 +316,39 @@ namespace ocean
 
     __syncthreads();
   }
+
+  //|---------------------- tile geometry shared by both passes ----------------
+
+#ifndef OCEAN_COL_THREADS
+#define OCEAN_COL_THREADS 512
+#endif
+#ifndef OCEAN_COL_CPT
+#define OCEAN_COL_CPT 2             // adjacent columns per thread: 2 (16-byte accesses) or 1
+#endif
+
+#ifndef OCEAN_HALO_BUFFER
+#define OCEAN_HALO_BUFFER 0
+#endif
+
+  // a column-pass tile is W columns wide; the central differences of ocean.map need the height of the two
+  // columns next to it (periodic).  Reading those out of the blocked spectrum touches a whole 64-byte run per
+  // 8-byte value (measured: 168 MB fetched for 109 MB needed at 1024^2 x 4).  Two remedies:
+  //   OCEAN_HALO_BUFFER = 0: tiles are dealt to XCDs in contiguous bands (tile_of_block), so the runs a halo
+  //     column touches are the ones the neighbouring tile's workgroup, on the same XCD at about the same time,
+  //     loads anyway: the second toucher hits L2.
+  //   OCEAN_HALO_BUFFER = 1: the row pass also writes them, column-major, into a small halo array
+  //     halo[tile][0][y] = column tile*W - 1, halo[tile][1][y] = column tile*W + W (costs the row pass
+  //     scattered 8-byte stores).
+  template<int N>
+  struct TileCfg
+  {
+    static constexpr int T = Plan<N>::T;
+    static constexpr int WC = (OCEAN_COL_THREADS / T) < 1 ? 1 : (OCEAN_COL_THREADS / T) > 8 ? 8 : (OCEAN_COL_THREADS / T);
+    static constexpr int W = OCEAN_COL_CPT * WC;
+    static constexpr int TILES = N / W;
+
+    static_assert(N % W == 0 && T % W == 0, "tile width must divide the thread stride of a row");
+  };
 
   //|---------------------- row pass ------------------------------------------
 
@@ -278,9 +363,6 @@ namespace ocean
 #endif
 #ifndef OCEAN_ROW_GROUPS
 #define OCEAN_ROW_GROUPS 1          // row groups a workgroup processes back to back (input prefetch depth 1)
-#endif
-#ifndef OCEAN_COL_THREADS
-#define OCEAN_COL_THREADS 512
 #endif
 #ifndef OCEAN_COL_MINWAVES
 #define OCEAN_COL_MINWAVES 1
@@ -395,9 +477,31 @@ namespace ocean
     float2 const *h0 = a.h0 + cascade * plane;
     float *phase = a.phase + cascade * plane;
     cf *spec = a.spec + cascade * 3 * plane;
+    cf *halo = a.halo + (size_t)cascade * TileCfg<N>::TILES * 2 * N;
     float const *omega = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
 
+    // this thread's columns t + T s all sit at the same place inside their tile: last column -> left halo of the
+    // next tile, first column -> right halo of the previous one
+    constexpr int W = TileCfg<N>::W;
+    constexpr int NT = TileCfg<N>::TILES;
+    int const halorole = (t % W == W - 1) ? 0 : (t % W == 0) ? 1 : -1;
+
     bool const advance = a.ndt > 0;
+
+#if defined(OCEAN_ROW_STAGGER) && OCEAN_ROW_STAGGER > 0
+    // experiment: break the chip-wide load / compute / store lockstep of the first generation of workgroups
+    {
+      // workgroups b, b + 256, b + 512 of the first generation are the ones that share a CU (8 XCDs x 32 CUs)
+      int const lag = ((blockIdx.x + gridDim.x * blockIdx.y) >> 8) % OCEAN_ROW_STAGGER_MOD;
+      for(int i = 0; i < lag * OCEAN_ROW_STAGGER; ++i)
+        __builtin_amdgcn_s_sleep(100);
+    }
+#endif
+
+#ifdef OCEAN_STAMPS
+    unsigned long long *stampbase = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+#endif
+    OCEAN_STAMP(0);
 
     typename L::Twiddles w;
     L::load_twiddles(a.tw, t, w);
@@ -443,12 +547,16 @@ namespace ocean
         }
       }
 
+      OCEAN_STAMP(1);
+
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
         h[s] = sim_height(in.hk[s], in.hm[s], in.ph[s]);
         kinv[s] = kinv_of(wavevector(t + T * s, N, cc.scale), ky);
       }
+
+      OCEAN_STAMP(2);
 
       order_fence();
 
@@ -473,9 +581,11 @@ namespace ocean
           v[2 % K][s] = cf{ h[s].y * kyn, -h[s].x * kyn };
         }
 
+        OCEAN_STAMP(3);
 #ifndef OCEAN_ABLATE_ROWFFT
         fft_lines<N, K>(v, t, line, P::LINE, midtab, w, true);
 #endif
+        OCEAN_STAMP(4);
 
         #pragma unroll
         for(int field = 0; field < K; ++field)
@@ -487,6 +597,21 @@ namespace ocean
             if (v[field][s].x == 123456.789f)
 #endif
             spec[field * plane + blocked<N>(y, t + T * s)] = v[field][s];
+          }
+        }
+
+        if (OCEAN_HALO_BUFFER && halorole >= 0)
+        {
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+          {
+            int tile = (t + T * s) / W;
+            int dst = (halorole == 0) ? (tile + 1) % NT : (tile + NT - 1) % NT;
+
+#ifdef OCEAN_ABLATE_ROWSTORE
+            if (v[0][s].x == 123456.789f)
+#endif
+            halo[((size_t)dst * 2 + halorole) * N + y] = v[0][s];
           }
         }
       }
@@ -510,8 +635,22 @@ namespace ocean
           #pragma unroll
           for(int s = 0; s < E; ++s)
             spec[field * plane + blocked<N>(y, t + T * s)] = v[0][s];
+
+          if (OCEAN_HALO_BUFFER && field == 0 && halorole >= 0)
+          {
+            #pragma unroll
+            for(int s = 0; s < E; ++s)
+            {
+              int tile = (t + T * s) / W;
+              int dst = (halorole == 0) ? (tile + 1) % NT : (tile + NT - 1) % NT;
+
+              halo[((size_t)dst * 2 + halorole) * N + y] = v[0][s];
+            }
+          }
         }
       }
+
+      OCEAN_STAMP(5);
 
       order_fence();
     }
@@ -519,17 +658,13 @@ namespace ocean
 
   //|---------------------- column pass + map ---------------------------------
 
-#ifndef OCEAN_COL_CPT
-#define OCEAN_COL_CPT 2             // adjacent columns per thread: 2 (16-byte accesses) or 1
-#endif
-
   template<int N>
   struct ColCfg
   {
     static constexpr int T = Plan<N>::T;
     static constexpr int CPT = OCEAN_COL_CPT;
-    static constexpr int WC = (OCEAN_COL_THREADS / T) < 1 ? 1 : (OCEAN_COL_THREADS / T) > 8 ? 8 : (OCEAN_COL_THREADS / T);   // threads across a tile row
-    static constexpr int W = CPT * WC;                                  // tile width in columns
+    static constexpr int WC = TileCfg<N>::WC;                           // threads across a tile row
+    static constexpr int W = TileCfg<N>::W;                             // tile width in columns
     static constexpr int THREADS = WC * T;
     static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_COL_MINWAVES : 1;
     static constexpr int CS = Plan<N>::LINE + 2;                        // LDS line stride (complex), == 2 mod 16
@@ -590,16 +725,38 @@ namespace ocean
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
       midtab[i] = L::midtab_entry(a.tw, i);
 
+    // blocks are dealt round-robin over the 8 XCDs (speed only): give each XCD a contiguous band of tiles so that
+    // neighbouring tiles, which share their border columns' cache lines, meet in the same L2
+    constexpr int NT = TileCfg<N>::TILES;
+    int const tile = (NT % 8 == 0) ? (int)(blockIdx.x & 7) * (NT / 8) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+
     int const cascade = blockIdx.y;
-    int const x0 = blockIdx.x * W;
+    int const x0 = tile * W;
 
     CascadeConst const cc = a.casc[cascade];
 
     size_t const plane = (size_t)N * N;
 
     cf const *spec = a.spec + cascade * 3 * plane;
+    cf const *halocols = a.halo + ((size_t)cascade * NT + tile) * 2 * N;
+    (void)halocols;
     float4 *layer0 = a.maps + (size_t)cascade * 2 * plane;
     float4 *layer1 = layer0 + plane;
+
+#if defined(OCEAN_COL_STAGGER) && OCEAN_COL_STAGGER > 0
+    {
+      // one workgroup per CU: delay every other CU of an XCD so that half the chip transforms while the other
+      // half is in its load or store phase
+      int const lag = ((blockIdx.x + gridDim.x * blockIdx.y) >> 3) % OCEAN_COL_STAGGER_MOD;
+      for(int i = 0; i < lag * OCEAN_COL_STAGGER; ++i)
+        __builtin_amdgcn_s_sleep(100);
+    }
+#endif
+
+#ifdef OCEAN_STAMPS
+    unsigned long long *stampbase = a.stamps + ((size_t)(gridDim.y + blockIdx.y) * 8192 + blockIdx.x) * 16;
+#endif
+    OCEAN_STAMP(0);
 
     // thread roles.  halo rounds: line slot hc = thread / T, row group ht = thread % T.
     // main rounds: column group cp (fastest over lanes) = columns xa .. xa + CPT - 1; row group t.
@@ -618,7 +775,6 @@ namespace ocean
     for(int hr = 0; hr < HR; ++hr)
     {
       int const side = hr * WC + hc;
-      int const hx = (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
 
       if (side < 2)
       {
@@ -627,8 +783,10 @@ namespace ocean
         {
 #ifdef OCEAN_ABLATE_COLLOAD
           vh[hr][s] = cf{ 0.01f * (float)(ht & 31), 0.02f * (float)s };
+#elif OCEAN_HALO_BUFFER
+          vh[hr][s] = halocols[side * N + ht + T * s];
 #else
-          vh[hr][s] = spec[blocked<N>(ht + T * s, hx)];
+          vh[hr][s] = spec[blocked<N>(ht + T * s, (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1)))];
 #endif
         }
       }
@@ -665,7 +823,11 @@ namespace ocean
         for(int s = 0; s < E; ++s)
           v[0][s] = vh[hr][s];
 
+        OCEAN_STAMP(1);
+
         fft_lines<N, 1>(v, ht, lines + hc * C::CS, C::CS, midtab, hw, halo);
+
+        OCEAN_STAMP(2);
 
         if (halo)
         {
@@ -715,9 +877,11 @@ namespace ocean
           v[c][s] = q[field & 1][s].get(c);
       }
 
+      OCEAN_STAMP(3 + 2 * field);
 #ifndef OCEAN_ABLATE_COLFFT
       fft_lines<N, CPT>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
 #endif
+      OCEAN_STAMP(4 + 2 * field);
 
       #pragma unroll
       for(int c = 0; c < CPT; ++c)
@@ -744,6 +908,8 @@ namespace ocean
     }
 
     __syncthreads();
+
+    OCEAN_STAMP(9);
 
     float const *left = (cp == 0) ? dzhalo : own - C::SY;
     float const *right = (cp == WC - 1) ? dzhalo + C::SY : own + CPT * C::SY;
@@ -779,6 +945,8 @@ namespace ocean
         }
       }
     }
+
+    OCEAN_STAMP(10);
   }
 
   //|---------------------- phase-only advance --------------------------------

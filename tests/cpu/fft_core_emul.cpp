@@ -48,6 +48,16 @@ static void run_line(float const *in, float *out)
     for(int t = 0; t < P::T; ++t) L::template mid_load<2>(R(t), t, line.data(), midtab.data(), w[t]);
     for(int t = 0; t < P::T; ++t) L::template mid_store<2>(R(t), t, line.data());
   }
+  if (P::NP >= 5)
+  {
+    for(int t = 0; t < P::T; ++t) L::template mid_load<3>(R(t), t, line.data(), midtab.data(), w[t]);
+    for(int t = 0; t < P::T; ++t) L::template mid_store<3>(R(t), t, line.data());
+  }
+  if (P::NP >= 6)
+  {
+    for(int t = 0; t < P::T; ++t) L::template mid_load<4>(R(t), t, line.data(), midtab.data(), w[t]);
+    for(int t = 0; t < P::T; ++t) L::template mid_store<4>(R(t), t, line.data());
+  }
   for(int t = 0; t < P::T; ++t) L::last(R(t), t, line.data(), w[t]);
 
   for(int t = 0; t < P::T; ++t)
