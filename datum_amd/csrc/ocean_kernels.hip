@@ -61,9 +61,61 @@ namespace ocean
 #endif
 
   template<int N>
-  __host__ __device__ __forceinline__ size_t blocked(int y, int x)
+  __host__ __device__ __forceinline__ constexpr size_t blocked(int y, int x)
   {
     return ((size_t)((y >> 3) * (N / 8) + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7);
+  }
+
+  //|---------------------- buffer addressing ----------------------------------
+  // Global accesses whose addresses differ between a thread's slots only by a wave-uniform amount go through
+  // buffer instructions: one 32-bit VGPR offset per thread plus an SGPR offset per access, instead of a 64-bit
+  // VGPR address computed per access (which was ~18 % of the VALU instructions of these kernels).
+
+  typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(void const *base, size_t bytes)
+  {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes), 0x00020000);
+  }
+
+  __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, 0));
+  }
+
+  __device__ __forceinline__ float2 buf_load_f32x2(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, voffset, soffset, 0));
+  }
+
+  __device__ __forceinline__ cf buf_load_cf(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    return __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(r, voffset, soffset, 0));
+  }
+
+  __device__ __forceinline__ float4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0));
+  }
+
+  // Stores: the per-access part goes into the VGPR offset (one v_add_u32), not into an SGPR.  A 128-bit buffer
+  // store with an SGPR offset was observed on gfx950 / ROCm 7.2 to store stale x, y components in the last lanes of
+  // each 16-lane group when the next VALU instruction rewrote its data registers: hipcc enforces the "VALU write of
+  // VMEM store data" wait states only when soffset is not a register (tools/dbg/colerr.py found it).
+  __device__ __forceinline__ void buf_store_f32(float v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voffset + soffset, 0, 0);
+  }
+
+  __device__ __forceinline__ void buf_store_cf(cf v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, v), r, voffset + soffset, 0, 0);
+  }
+
+  __device__ __forceinline__ void buf_store_f32x4(float4 v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, voffset + soffset, 0, 0);
   }
 
   //|---------------------- update_ocean --------------------------------------
@@ -205,14 +257,83 @@ namespace ocean
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  //|---------------------- per-thread twiddles of a line transform ------------
+
+  template<int N, bool QUAD = QuadFFT<N>::ENABLED> struct LineTw;
+
+  template<int N> struct LineTw<N, false>
+  {
+    typedef typename LineFFT<N>::Twiddles type;
+    static __device__ __forceinline__ void load(cf const *tw, int t, type &w) { LineFFT<N>::load_twiddles(tw, t, w); }
+  };
+
+  template<int N> struct LineTw<N, true>
+  {
+    typedef QuadTwiddles type;
+    static __device__ __forceinline__ void load(cf const *tw, int t, type &w) { quad_load_twiddles(tw, t, w); }
+  };
+
+  // N = 1024: two radix-32 passes on quads, one exchange (ocean_fft_core.h).  Every quad of an active wave
+  // must be fully active (DPP): `active` is uniform per wave at every call site.
+  template<int K>
+  __device__ __forceinline__ void fft_lines_quad(cf (&v)[K][8], int t, cf *line, int linestride, QuadTwiddles const &w, bool active)
+  {
+    int const a = t & 3;
+    int const j = t >> 2;
+
+    if (active)
+    {
+      int const base = quad_swizzle(32 * j + 8 * bitrev2(a));
+
+      #pragma unroll
+      for(int k = 0; k < K; ++k)
+      {
+        quad_radix32_local(v[k], w);
+        quad_radix4_lanes(v[k], a);
+
+        #pragma unroll
+        for(int q = 0; q < 8; ++q)
+          line[k * linestride + (base ^ q)] = v[k][q];
+      }
+    }
+
+    __syncthreads();
+
+    if (active)
+    {
+      int const base = quad_swizzle(j + 32 * a);
+
+      #pragma unroll
+      for(int k = 0; k < K; ++k)
+      {
+        #pragma unroll
+        for(int b = 0; b < 8; ++b)
+          v[k][b] = cmul(line[k * linestride + base + 128 * b], w.pass1[b]);
+
+        quad_radix32_local(v[k], w);
+        quad_radix4_lanes(v[k], a);
+      }
+    }
+
+    __syncthreads();
+  }
+
   //|---------------------- line FFTs with workgroup barriers ------------------
   // K independent lines per thread go through the exchange phases together, so the number of barriers per
   // workgroup does not grow with K (one line per barrier phase is what the reference's per-field loop does).
 
   template<int N, int K>
-  __device__ __forceinline__ void fft_lines(cf (&v)[K][Plan<N>::E], int t, cf *line, int linestride, cf const *midtab, typename LineFFT<N>::Twiddles const &w, bool active)
+  __device__ __forceinline__ void fft_lines(cf (&v)[K][Plan<N>::E], int t, cf *line, int linestride, cf const *midtab, typename LineTw<N>::type const &w, bool active)
   {
     typedef LineFFT<N> L;
+
+    if constexpr (QuadFFT<N>::ENABLED)
+    {
+      fft_lines_quad<K>(v, t, line, linestride, w, active);
+      return;
+    }
+    else
+    {
 
     if (active)
     {
@@ -315,6 +436,7 @@ namespace ocean
     }
 
     __syncthreads();
+    }
   }
 
   //|---------------------- tile geometry shared by both passes ----------------
@@ -416,21 +538,30 @@ namespace ocean
   __device__ __forceinline__ void load_sim_inputs(SimInputs<N> &in, float2 const *h0, float const *phase, float const *omega, int y, int t, bool advance)
   {
     constexpr int E = Plan<N>::E;
-    constexpr int T = Plan<N>::T;
+
+    // a thread's elements are a wave-uniform distance apart: one VGPR offset, SGPR offsets per slot.  The
+    // mirror row runs backwards, so its base is the last slot's element.
+    constexpr int DX = elem_in<N>(0, 1) - elem_in<N>(0, 0);
+
+    __amdgpu_buffer_rsrc_t rph = make_rsrc(phase, (size_t)N * N * sizeof(float));
+    __amdgpu_buffer_rsrc_t rh0 = make_rsrc(h0, (size_t)N * N * sizeof(float2));
+
+    int const x0 = elem_in<N>(t, 0);
+    int const e0 = y * N + x0;
+    int const m0 = (N - 1 - y) * N + (N - 1 - x0 - DX * (E - 1));
 
     #pragma unroll
     for(int s = 0; s < E; ++s)
     {
-      int x = t + T * s;
-
 #ifdef OCEAN_ABLATE_ROWLOAD
+      int x = elem_in<N>(t, s);
       in.ph[s] = 0.001f * (float)x;
       in.hk[s] = make_float2(0.01f * (float)(x & 15), 0.02f);
       in.hm[s] = make_float2(0.03f, 0.01f * (float)(y & 15));
 #else
-      in.ph[s] = phase[(size_t)y * N + x];
-      in.hk[s] = h0[(size_t)y * N + x];
-      in.hm[s] = h0[(size_t)(N - 1 - y) * N + (N - 1 - x)];
+      in.ph[s] = buf_load_f32(rph, e0 * 4, DX * s * 4);
+      in.hk[s] = buf_load_f32x2(rh0, e0 * 8, DX * s * 8);
+      in.hm[s] = buf_load_f32x2(rh0, m0 * 8, DX * (E - 1 - s) * 8);
 #endif
     }
 
@@ -441,7 +572,7 @@ namespace ocean
 #ifdef OCEAN_ABLATE_ROWLOAD
         in.om[s] = 1.0f + 0.001f * (float)s;
 #else
-        in.om[s] = dispersion_lookup(omega, t + T * s, y, N);
+        in.om[s] = dispersion_lookup(omega, elem_in<N>(t, s), y, N);
 #endif
     }
   }
@@ -480,11 +611,20 @@ namespace ocean
     cf *halo = a.halo + (size_t)cascade * TileCfg<N>::TILES * 2 * N;
     float const *omega = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
 
+    // buffer addressing (see buf_*): slot-to-slot distances of a thread's elements, in elements
+    constexpr int DXI = elem_in<N>(0, 1) - elem_in<N>(0, 0);                                            // row-major, inputs
+    constexpr int DBO = (int)(blocked<N>(0, elem_out<N>(0, 1)) - blocked<N>(0, elem_out<N>(0, 0)));     // blocked, outputs
+
+    static_assert(DXI % 8 == 0 && (elem_out<N>(0, 1) - elem_out<N>(0, 0)) % 8 == 0, "slots must be whole 8-column blocks apart");
+
+    __amdgpu_buffer_rsrc_t rphase = make_rsrc(phase, plane * sizeof(float));
+    __amdgpu_buffer_rsrc_t rspec = make_rsrc(spec, 3 * plane * sizeof(cf));
+
     // this thread's columns t + T s all sit at the same place inside their tile: last column -> left halo of the
     // next tile, first column -> right halo of the previous one
     constexpr int W = TileCfg<N>::W;
     constexpr int NT = TileCfg<N>::TILES;
-    int const halorole = (t % W == W - 1) ? 0 : (t % W == 0) ? 1 : -1;
+    int const halorole = (elem_out<N>(t, 0) % W == W - 1) ? 0 : (elem_out<N>(t, 0) % W == 0) ? 1 : -1;   // same for every slot: slots differ by multiples of 32
 
     bool const advance = a.ndt > 0;
 
@@ -503,8 +643,8 @@ namespace ocean
 #endif
     OCEAN_STAMP(0);
 
-    typename L::Twiddles w;
-    L::load_twiddles(a.tw, t, w);
+    typename LineTw<N>::type w;
+    LineTw<N>::load(a.tw, t, w);
 
     // GPW row groups one after the other.  The inputs of group g + 1 are requested right after group g's
     // ocean.sim, so their latency is covered by group g's butterflies and barriers; the compiler barriers pin
@@ -543,7 +683,7 @@ namespace ocean
 #ifdef OCEAN_ABLATE_ROWSTORE
           if (in.ph[s] == 123456.789f)
 #endif
-          phase[(size_t)y * N + t + T * s] = in.ph[s];
+          buf_store_f32(in.ph[s], rphase, (y * N + elem_in<N>(t, 0)) * 4, DXI * s * 4);
         }
       }
 
@@ -553,7 +693,7 @@ namespace ocean
       for(int s = 0; s < E; ++s)
       {
         h[s] = sim_height(in.hk[s], in.hm[s], in.ph[s]);
-        kinv[s] = kinv_of(wavevector(t + T * s, N, cc.scale), ky);
+        kinv[s] = kinv_of(wavevector(elem_in<N>(t, s), N, cc.scale), ky);
       }
 
       OCEAN_STAMP(2);
@@ -573,7 +713,7 @@ namespace ocean
         #pragma unroll
         for(int s = 0; s < E; ++s)
         {
-          float kx = wavevector(t + T * s, N, cc.scale) * kinv[s];
+          float kx = wavevector(elem_in<N>(t, s), N, cc.scale) * kinv[s];
           float kyn = ky * kinv[s];
 
           v[0][s] = h[s];
@@ -596,7 +736,7 @@ namespace ocean
 #ifdef OCEAN_ABLATE_ROWSTORE
             if (v[field][s].x == 123456.789f)
 #endif
-            spec[field * plane + blocked<N>(y, t + T * s)] = v[field][s];
+            buf_store_cf(v[field][s], rspec, (int)blocked<N>(y, elem_out<N>(t, 0)) * 8, (int)((field * plane + (size_t)DBO * s) * 8));
           }
         }
 
@@ -605,7 +745,7 @@ namespace ocean
           #pragma unroll
           for(int s = 0; s < E; ++s)
           {
-            int tile = (t + T * s) / W;
+            int tile = elem_out<N>(t, s) / W;
             int dst = (halorole == 0) ? (tile + 1) % NT : (tile + NT - 1) % NT;
 
 #ifdef OCEAN_ABLATE_ROWSTORE
@@ -625,7 +765,7 @@ namespace ocean
           #pragma unroll
           for(int s = 0; s < E; ++s)
           {
-            float kc = ((field == 1) ? wavevector(t + T * s, N, cc.scale) : ky) * kinv[s];
+            float kc = ((field == 1) ? wavevector(elem_in<N>(t, s), N, cc.scale) : ky) * kinv[s];
 
             v[0][s] = (field == 0) ? h[s] : cf{ h[s].y * kc, -h[s].x * kc };
           }
@@ -634,14 +774,14 @@ namespace ocean
 
           #pragma unroll
           for(int s = 0; s < E; ++s)
-            spec[field * plane + blocked<N>(y, t + T * s)] = v[0][s];
+            buf_store_cf(v[0][s], rspec, (int)blocked<N>(y, elem_out<N>(t, 0)) * 8, (int)((field * plane + (size_t)DBO * s) * 8));
 
           if (OCEAN_HALO_BUFFER && field == 0 && halorole >= 0)
           {
             #pragma unroll
             for(int s = 0; s < E; ++s)
             {
-              int tile = (t + T * s) / W;
+              int tile = elem_out<N>(t, s) / W;
               int dst = (halorole == 0) ? (tile + 1) % NT : (tile + NT - 1) % NT;
 
               halo[((size_t)dst * 2 + halorole) * N + y] = v[0][s];
@@ -691,6 +831,7 @@ namespace ocean
   {
     cf v;
     __device__ __forceinline__ void load(cf const *p) { v = *p; }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voffset, int soffset) { v = buf_load_cf(r, voffset, soffset); }
     __device__ __forceinline__ cf get(int) const { return v; }
   };
 
@@ -698,6 +839,7 @@ namespace ocean
   {
     float4 v;
     __device__ __forceinline__ void load(cf const *p) { v = *reinterpret_cast<float4 const*>(p); }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voffset, int soffset) { v = buf_load_f32x4(r, voffset, soffset); }
     __device__ __forceinline__ cf get(int i) const { return i == 0 ? cf{ v.x, v.y } : cf{ v.z, v.w }; }
   };
 
@@ -741,7 +883,15 @@ namespace ocean
     cf const *halocols = a.halo + ((size_t)cascade * NT + tile) * 2 * N;
     (void)halocols;
     float4 *layer0 = a.maps + (size_t)cascade * 2 * plane;
-    float4 *layer1 = layer0 + plane;
+
+    // buffer addressing (see buf_*): slot-to-slot distances of a thread's rows
+    constexpr int DBI = (int)(blocked<N>(elem_in<N>(0, 1), 0) - blocked<N>(elem_in<N>(0, 0), 0));      // blocked spectrum, inputs (elements)
+    constexpr int DYO = elem_out<N>(0, 1) - elem_out<N>(0, 0);                                         // map rows, outputs
+
+    static_assert((elem_in<N>(0, 1) - elem_in<N>(0, 0)) % 8 == 0, "slots must be whole 8-row blocks apart");
+
+    __amdgpu_buffer_rsrc_t rspec = make_rsrc(spec, 3 * plane * sizeof(cf));
+    __amdgpu_buffer_rsrc_t rmaps = make_rsrc(layer0, 2 * plane * sizeof(float4));
 
 #if defined(OCEAN_COL_STAGGER) && OCEAN_COL_STAGGER > 0
     {
@@ -763,8 +913,9 @@ namespace ocean
     int const hc = threadIdx.x / T;
     int const ht = threadIdx.x % T;
 
-    int const cp = threadIdx.x % WC;
-    int const t = threadIdx.x / WC;
+    // (with quad butterflies the four lanes of a quad must be the four threads 4j .. 4j+3 of one line)
+    int const cp = QuadFFT<N>::ENABLED ? (int)(threadIdx.x >> 2) % WC : (int)threadIdx.x % WC;
+    int const t = QuadFFT<N>::ENABLED ? (int)((threadIdx.x / (4 * WC)) << 2 | (threadIdx.x & 3)) : (int)threadIdx.x / WC;
     int const xa = x0 + CPT * cp;
 
     // all requests for the first two rounds go out before any transform: the halo columns (height only) and
@@ -784,9 +935,9 @@ namespace ocean
 #ifdef OCEAN_ABLATE_COLLOAD
           vh[hr][s] = cf{ 0.01f * (float)(ht & 31), 0.02f * (float)s };
 #elif OCEAN_HALO_BUFFER
-          vh[hr][s] = halocols[side * N + ht + T * s];
+          vh[hr][s] = halocols[side * N + elem_in<N>(ht, s)];
 #else
-          vh[hr][s] = spec[blocked<N>(ht + T * s, (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1)))];
+          vh[hr][s] = buf_load_cf(rspec, (int)blocked<N>(elem_in<N>(ht, 0), (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1))) * 8, DBI * s * 8);
 #endif
         }
       }
@@ -800,14 +951,14 @@ namespace ocean
 #ifdef OCEAN_ABLATE_COLLOAD
       q[0][s].load(midtab + ((t + s + cp) & 31));
 #else
-      q[0][s].load(spec + blocked<N>(t + T * s, xa));
+      q[0][s].load(rspec, (int)blocked<N>(elem_in<N>(t, 0), xa) * 8, DBI * s * 8);
 #endif
     }
 
     // halo rounds: height of the two columns bordering the tile (periodic, map.comp:58)
     {
-      typename L::Twiddles hw;
-      L::load_twiddles(a.tw, ht, hw);
+      typename LineTw<N>::type hw;
+      LineTw<N>::load(a.tw, ht, hw);
 
       #pragma unroll
       for(int hr = 0; hr < HR; ++hr)
@@ -815,7 +966,7 @@ namespace ocean
         int const side = hr * WC + hc;
         bool const halo = side < 2;
         int const hx = (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
-        float const hsigma = ((hx + ht) & 1) ? -1.0f : 1.0f;
+        float const hsigma = ((hx + elem_out<N>(ht, 0)) & 1) ? -1.0f : 1.0f;
 
         cf v[1][E];
 
@@ -833,20 +984,20 @@ namespace ocean
         {
           #pragma unroll
           for(int s = 0; s < E; ++s)
-            dzhalo[side * C::SY + ht + T * s] = v[0][s].x * hsigma;
+            dzhalo[side * C::SY + elem_out<N>(ht, s)] = v[0][s].x * hsigma;
         }
       }
     }
 
-    typename L::Twiddles w;
-    L::load_twiddles(a.tw, t, w);
+    typename LineTw<N>::type w;
+    LineTw<N>::load(a.tw, t, w);
 
-    // (-1)^(x+y) of map.comp:60; y = t + T s with T even: fixed per thread and column, alternating over columns
+    // (-1)^(x+y) of map.comp:60; a thread's rows differ by even amounts: fixed per thread and column, alternating over columns
     float sig[CPT];
 
     #pragma unroll
     for(int c = 0; c < CPT; ++c)
-      sig[c] = ((xa + c + t) & 1) ? -1.0f : 1.0f;
+      sig[c] = ((xa + c + elem_out<N>(t, 0)) & 1) ? -1.0f : 1.0f;
 
     float dx[CPT][E], dy[CPT][E], dz[CPT][E];
 
@@ -862,7 +1013,7 @@ namespace ocean
 #ifdef OCEAN_ABLATE_COLLOAD
           q[(field + 1) & 1][s].load(midtab + ((t + s + cp + field) & 31));
 #else
-          q[(field + 1) & 1][s].load(spec + (field + 1) * plane + blocked<N>(t + T * s, xa));
+          q[(field + 1) & 1][s].load(rspec, (int)blocked<N>(elem_in<N>(t, 0), xa) * 8, (int)(((field + 1) * plane + (size_t)DBI * s) * 8));
 #endif
         }
       }
@@ -904,7 +1055,7 @@ namespace ocean
     {
       #pragma unroll
       for(int s = 0; s < E; ++s)
-        own[c * C::SY + t + T * s] = dz[c][s];
+        own[c * C::SY + elem_out<N>(t, s)] = dz[c][s];
     }
 
     __syncthreads();
@@ -918,13 +1069,13 @@ namespace ocean
     #pragma unroll
     for(int s = 0; s < E; ++s)
     {
-      int y = t + T * s;
+      int y = elem_out<N>(t, s);
       int yu = (y + N - 1) & (N - 1);
       int yd = (y + 1) & (N - 1);
 
       float nz = cc.nz;
 
-      size_t o = (size_t)y * N + xa;
+      int const o0 = (elem_out<N>(t, 0) * N + xa) * 16;                 // byte offset of this thread's first texel, slot 0
 
       #pragma unroll
       for(int c = 0; c < CPT; ++c)
@@ -940,8 +1091,8 @@ namespace ocean
         if (nx * inv + dx[c][s] + dy[c][s] == 123456.789f)
 #endif
         {
-          layer0[o + c] = make_float4(dx[c][s], dy[c][s], dz[c][s], 0.0f);
-          layer1[o + c] = make_float4(nx * inv, ny * inv, nz * inv, 0.0f);
+          buf_store_f32x4(make_float4(dx[c][s], dy[c][s], dz[c][s], 0.0f), rmaps, o0, (DYO * s * N + c) * 16);
+          buf_store_f32x4(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, (int)(((size_t)DYO * s * N + c + plane) * 16));
         }
       }
     }
