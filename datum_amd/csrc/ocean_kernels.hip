@@ -439,13 +439,73 @@ namespace ocean
     }
   }
 
+  // two independent line transforms, each with its own thread role, line and twiddles, through ONE set of
+  // barriers (generic path only): lets the column pass transform its halo columns together with field 0
+  template<int N>
+  __device__ __forceinline__ void fft_pair(cf (&va)[Plan<N>::E], int ta, cf *linea, typename LineFFT<N>::Twiddles const &wa, bool acta,
+                                           cf (&vb)[Plan<N>::E], int tb, cf *lineb, typename LineFFT<N>::Twiddles const &wb, bool actb,
+                                           cf const *midtab)
+  {
+    typedef LineFFT<N> L;
+
+    if (acta) L::pass0(va, ta, linea);
+    if (actb) L::pass0(vb, tb, lineb);
+
+    __syncthreads();
+
+    if (Plan<N>::NP >= 3)
+    {
+      if (acta) L::template mid_load<1>(va, ta, linea, midtab, wa);
+      if (actb) L::template mid_load<1>(vb, tb, lineb, midtab, wb);
+      __syncthreads();
+      if (acta) L::template mid_store<1>(va, ta, linea);
+      if (actb) L::template mid_store<1>(vb, tb, lineb);
+      __syncthreads();
+    }
+
+    if (Plan<N>::NP >= 4)
+    {
+      if (acta) L::template mid_load<2>(va, ta, linea, midtab, wa);
+      if (actb) L::template mid_load<2>(vb, tb, lineb, midtab, wb);
+      __syncthreads();
+      if (acta) L::template mid_store<2>(va, ta, linea);
+      if (actb) L::template mid_store<2>(vb, tb, lineb);
+      __syncthreads();
+    }
+
+    if (Plan<N>::NP >= 5)
+    {
+      if (acta) L::template mid_load<3>(va, ta, linea, midtab, wa);
+      if (actb) L::template mid_load<3>(vb, tb, lineb, midtab, wb);
+      __syncthreads();
+      if (acta) L::template mid_store<3>(va, ta, linea);
+      if (actb) L::template mid_store<3>(vb, tb, lineb);
+      __syncthreads();
+    }
+
+    if (Plan<N>::NP >= 6)
+    {
+      if (acta) L::template mid_load<4>(va, ta, linea, midtab, wa);
+      if (actb) L::template mid_load<4>(vb, tb, lineb, midtab, wb);
+      __syncthreads();
+      if (acta) L::template mid_store<4>(va, ta, linea);
+      if (actb) L::template mid_store<4>(vb, tb, lineb);
+      __syncthreads();
+    }
+
+    if (acta) L::last(va, ta, linea, wa);
+    if (actb) L::last(vb, tb, lineb, wb);
+
+    __syncthreads();
+  }
+
   //|---------------------- tile geometry shared by both passes ----------------
 
 #ifndef OCEAN_COL_THREADS
 #define OCEAN_COL_THREADS 512
 #endif
 #ifndef OCEAN_COL_CPT
-#define OCEAN_COL_CPT 2             // adjacent columns per thread: 2 (16-byte accesses) or 1
+#define OCEAN_COL_CPT 0             // adjacent columns per thread: 1, 2 (16-byte accesses), or 0 = by size
 #endif
 
 #ifndef OCEAN_HALO_BUFFER
@@ -466,7 +526,12 @@ namespace ocean
   {
     static constexpr int T = Plan<N>::T;
     static constexpr int WC = (OCEAN_COL_THREADS / T) < 1 ? 1 : (OCEAN_COL_THREADS / T) > 8 ? 8 : (OCEAN_COL_THREADS / T);
-    static constexpr int W = OCEAN_COL_CPT * WC;
+
+    // one column per thread keeps the column pass near 110 VGPRs = two 512-thread workgroups per CU (measured
+    // 53 us against 59 us for two columns per thread at 1024^2 x 4); from N = 2048 up a workgroup would then span
+    // only 1-2 columns and the halo columns would dominate, so two columns per thread there
+    static constexpr int CPT = (OCEAN_COL_CPT != 0) ? OCEAN_COL_CPT : (T <= 128 ? 1 : 2);
+    static constexpr int W = CPT * WC;
     static constexpr int TILES = N / W;
 
     static_assert(N % W == 0 && T % W == 0, "tile width must divide the thread stride of a row");
@@ -802,7 +867,7 @@ namespace ocean
   struct ColCfg
   {
     static constexpr int T = Plan<N>::T;
-    static constexpr int CPT = OCEAN_COL_CPT;
+    static constexpr int CPT = TileCfg<N>::CPT;
     static constexpr int WC = TileCfg<N>::WC;                           // threads across a tile row
     static constexpr int W = TileCfg<N>::W;                             // tile width in columns
     static constexpr int THREADS = WC * T;
@@ -811,11 +876,18 @@ namespace ocean
     static constexpr int SY = N + 4;                                    // height exchange: column stride (floats)
     static constexpr int HR = (2 + WC - 1) / WC;                        // halo rounds (1 unless WC == 1)
 
+#ifndef OCEAN_COL_FUSE_HALO
+#define OCEAN_COL_FUSE_HALO 0      // measured: no gain at 1024^2 x 4 (54.9 us fused vs 53.2 us), kept as an option
+#endif
+    // one column per thread: the two halo columns are transformed together with field 0 (their own two LDS
+    // lines, the same barriers) instead of in a round of their own, which at W = 4 was a quarter of the work
+    static constexpr bool FUSE = (OCEAN_COL_FUSE_HALO != 0) && CPT == 1 && WC >= 2 && !QuadFFT<N>::ENABLED;
+
     // LDS carve, in bytes: first middle-pass twiddles | heights of the two halo columns | W transform lines
     // (every column of the tile is in flight), later reused for the heights of the tile's own columns
     static constexpr size_t OFF_HALO = (size_t)LineFFT<N>::MIDTAB * sizeof(cf);
     static constexpr size_t OFF_MAIN = OFF_HALO + (size_t)2 * SY * sizeof(float);
-    static constexpr size_t MAIN_FFT = (size_t)(W > 2 ? W : 2) * CS * sizeof(cf);
+    static constexpr size_t MAIN_FFT = (size_t)(FUSE ? W + 2 : (W > 2 ? W : 2)) * CS * sizeof(cf);
     static constexpr size_t MAIN_DZ = (size_t)W * SY * sizeof(float);
     static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
 
@@ -956,10 +1028,11 @@ namespace ocean
     }
 
     // halo rounds: height of the two columns bordering the tile (periodic, map.comp:58)
-    {
-      typename LineTw<N>::type hw;
-      LineTw<N>::load(a.tw, ht, hw);
+    typename LineTw<N>::type hw;
+    LineTw<N>::load(a.tw, ht, hw);
 
+    if constexpr (!C::FUSE)
+    {
       #pragma unroll
       for(int hr = 0; hr < HR; ++hr)
       {
@@ -1030,7 +1103,29 @@ namespace ocean
 
       OCEAN_STAMP(3 + 2 * field);
 #ifndef OCEAN_ABLATE_COLFFT
-      fft_lines<N, CPT>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
+      if constexpr (C::FUSE)
+      {
+        if (field == 0)
+        {
+          // the halo columns ride along: threads hc < 2 carry a second line (slots W, W + 1)
+          bool const halo = hc < 2;
+          int const hx = (hc == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
+          float const hsigma = ((hx + elem_out<N>(ht, 0)) & 1) ? -1.0f : 1.0f;
+
+          fft_pair<N>(v[0], t, lines + cp * C::CS, w, true, vh[0], ht, lines + (W + hc) * C::CS, hw, halo, midtab);
+
+          if (halo)
+          {
+            #pragma unroll
+            for(int s = 0; s < E; ++s)
+              dzhalo[hc * C::SY + elem_out<N>(ht, s)] = vh[0][s].x * hsigma;
+          }
+        }
+        else
+          fft_lines<N, CPT>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
+      }
+      else
+        fft_lines<N, CPT>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
 #endif
       OCEAN_STAMP(4 + 2 * field);
 
