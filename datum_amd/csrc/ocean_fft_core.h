@@ -115,15 +115,18 @@ namespace ocean
     static constexpr int RL = N / ipow(E, NP - 1);
     static constexpr int M = E / RL;
     static constexpr int NS_LAST = N / RL;      // product of the radices before the last pass
-    static constexpr int LINE = QuadFFT<N>::ENABLED ? N : N + N / 16;   // LDS line length, in complex elements (padded unless swizzled)
+    // LDS line length in complex elements for index padding i + (i >> PS) (no padding when swizzled instead)
+    template<int PS> static constexpr int line() { return QuadFFT<N>::ENABLED ? N : N + (N >> PS); }
 
     static_assert(NP >= 2 && NP <= 6, "bad plan");
     static_assert(RL >= 2 && RL <= E && E % RL == 0, "bad plan");
     static_assert(ipow(E, NP - 1) * RL == N, "bad plan");
   };
 
-  // LDS index padding: one extra element every 16, breaks the power-of-two strides of the pass-0 stores
-  OC_HD constexpr int padidx(int i) { return i + (i >> 4); }
+  // LDS index padding: one extra element every 2^PS, breaks the power-of-two strides of the exchange stores.
+  // PS = 4 is the compact choice (row pass: three workgroups per CU fit); PS = 3 has fewer bank conflicts with
+  // the column pass's (column, row) lane order and is used there.
+  template<int PS> OC_HD constexpr int padidx(int i) { return i + (i >> PS); }
 
   //|---------------------- radix butterflies ---------------------------------
   // idft<R>: v[q] <- sum_r v[r] exp(+2 pi i q r / R), natural order
@@ -259,10 +262,24 @@ namespace ocean
   // tw[k] = exp(+2 pi i k / N), k < N   (built in double on the host: ocean_capi)
   // `line` points at this line's padded LDS region (Plan::LINE elements)
 
+  // per-thread twiddles kept in registers, each the first power of its pass; higher powers come from
+  // twiddle_powers.  last[m] = exp(2 pi i j / N) for the last pass's tasks j = t + T m (Ns = N / RL);
+  // mid[k] = exp(2 pi i (t % Ns) / (Ns E)) for middle pass k + 2 (Ns = E^(k+2)).
   template<int N>
+  struct LineTwiddles
+  {
+    static constexpr int NMIDREG = (Plan<N>::NP > 3) ? Plan<N>::NP - 3 : 1;
+
+    cf mid[NMIDREG];
+    cf last[Plan<N>::M];
+  };
+
+  template<int N, int PS = 4>
   struct LineFFT
   {
     typedef Plan<N> P;
+
+    static constexpr int LINE = P::template line<PS>();
 
     static constexpr int E = P::E;
     static constexpr int T = P::T;
@@ -272,13 +289,9 @@ namespace ocean
     // per-thread twiddles kept in registers, each the first power of its pass; higher powers come from
     // twiddle_powers.  last[m] = exp(2 pi i j / N) for the last pass's tasks j = t + T m (Ns = N / RL);
     // mid[k] = exp(2 pi i (t % Ns) / (Ns E)) for middle pass k + 2 (Ns = E^(k+2)).
-    static constexpr int NMIDREG = (P::NP > 3) ? P::NP - 3 : 1;
+    static constexpr int NMIDREG = LineTwiddles<N>::NMIDREG;
 
-    struct Twiddles
-    {
-      cf mid[NMIDREG];
-      cf last[M];
-    };
+    typedef LineTwiddles<N> Twiddles;
 
     static OC_HD void load_twiddles(cf const *tw, int t, Twiddles &w)
     {
@@ -312,7 +325,7 @@ namespace ocean
 
       OC_UNROLL
       for(int q = 0; q < E; ++q)
-        line[padidx(t * E + q)] = v[q];
+        line[padidx<PS>(t * E + q)] = v[q];
     }
 
     // middle pass PASS (1 <= PASS <= NP-2): Ns = E^PASS, radix E, task j = t.  load + twiddle + butterfly
@@ -321,7 +334,7 @@ namespace ocean
     {
       OC_UNROLL
       for(int r = 0; r < E; ++r)
-        v[r] = line[padidx(t + T * r)];
+        v[r] = line[padidx<PS>(t + T * r)];
 
       if (PASS == 1)
       {
@@ -353,7 +366,7 @@ namespace ocean
 
       OC_UNROLL
       for(int q = 0; q < E; ++q)
-        line[padidx(base + q * Ns)] = v[q];
+        line[padidx<PS>(base + q * Ns)] = v[q];
     }
 
     // last pass: Ns = N/RL, radix RL, tasks j = t + T m.  result slot m + q M holds X[t + T (m + q M)]
@@ -367,7 +380,7 @@ namespace ocean
         cf u[RL];
         OC_UNROLL
         for(int r = 0; r < RL; ++r)
-          u[r] = line[padidx(j + r * (N / RL))];
+          u[r] = line[padidx<PS>(j + r * (N / RL))];
 
         cf p[RL];
         twiddle_powers<RL>(w.last[m], p);

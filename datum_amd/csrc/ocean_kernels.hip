@@ -322,10 +322,10 @@ namespace ocean
   // K independent lines per thread go through the exchange phases together, so the number of barriers per
   // workgroup does not grow with K (one line per barrier phase is what the reference's per-field loop does).
 
-  template<int N, int K>
+  template<int N, int K, int PS>
   __device__ __forceinline__ void fft_lines(cf (&v)[K][Plan<N>::E], int t, cf *line, int linestride, cf const *midtab, typename LineTw<N>::type const &w, bool active)
   {
-    typedef LineFFT<N> L;
+    typedef LineFFT<N, PS> L;
 
     if constexpr (QuadFFT<N>::ENABLED)
     {
@@ -441,12 +441,12 @@ namespace ocean
 
   // two independent line transforms, each with its own thread role, line and twiddles, through ONE set of
   // barriers (generic path only): lets the column pass transform its halo columns together with field 0
-  template<int N>
+  template<int N, int PS>
   __device__ __forceinline__ void fft_pair(cf (&va)[Plan<N>::E], int ta, cf *linea, typename LineFFT<N>::Twiddles const &wa, bool acta,
                                            cf (&vb)[Plan<N>::E], int tb, cf *lineb, typename LineFFT<N>::Twiddles const &wb, bool actb,
                                            cf const *midtab)
   {
-    typedef LineFFT<N> L;
+    typedef LineFFT<N, PS> L;
 
     if (acta) L::pass0(va, ta, linea);
     if (actb) L::pass0(vb, tb, lineb);
@@ -565,7 +565,9 @@ namespace ocean
     static constexpr int GPW = (N / ROWS) % (16 * OCEAN_ROW_GROUPS) == 0 ? OCEAN_ROW_GROUPS : 1;    // row groups per workgroup, one after the other
     static constexpr int BLOCKS = N / (ROWS * GPW);                                    // workgroups per cascade
     static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_ROW_MINWAVES : 1;        // per SIMD
-    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)ROWS * K * Plan<N>::LINE) * sizeof(cf);
+    static constexpr int PS = 4;                                                       // LDS index padding (see padidx)
+    static constexpr int LINE = LineFFT<N, PS>::LINE;
+    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)ROWS * K * LINE) * sizeof(cf);
 
     static_assert(K == 1 || K == 3, "OCEAN_ROW_FIELDS must be 1 or 3");
   };
@@ -661,7 +663,7 @@ namespace ocean
     int const y0 = rowband_of_block<N>(blockIdx.x) * (C::ROWS * C::GPW) + r;
 
     cf *midtab = reinterpret_cast<cf*>(smem);
-    cf *line = midtab + L::MIDTAB + r * K * P::LINE;
+    cf *line = midtab + L::MIDTAB + r * K * C::LINE;
 
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
       midtab[i] = L::midtab_entry(a.tw, i);
@@ -720,7 +722,11 @@ namespace ocean
 
     order_fence();
 
+#ifdef OCEAN_ROW_UNROLL_GROUPS
+    #pragma unroll
+#else
     #pragma unroll 1
+#endif
     for(int g = 0; g < C::GPW; ++g)
     {
       int const y = y0 + g * C::ROWS;
@@ -788,7 +794,7 @@ namespace ocean
 
         OCEAN_STAMP(3);
 #ifndef OCEAN_ABLATE_ROWFFT
-        fft_lines<N, K>(v, t, line, P::LINE, midtab, w, true);
+        fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
 #endif
         OCEAN_STAMP(4);
 
@@ -835,7 +841,7 @@ namespace ocean
             v[0][s] = (field == 0) ? h[s] : cf{ h[s].y * kc, -h[s].x * kc };
           }
 
-          fft_lines<N, 1>(v, t, line, P::LINE, midtab, w, true);
+          fft_lines<N, 1, C::PS>(v, t, line, C::LINE, midtab, w, true);
 
           #pragma unroll
           for(int s = 0; s < E; ++s)
@@ -872,7 +878,14 @@ namespace ocean
     static constexpr int W = TileCfg<N>::W;                             // tile width in columns
     static constexpr int THREADS = WC * T;
     static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_COL_MINWAVES : 1;
-    static constexpr int CS = Plan<N>::LINE + 2;                        // LDS line stride (complex), == 2 mod 16
+#ifndef OCEAN_COL_PAD_SHIFT
+#define OCEAN_COL_PAD_SHIFT 3
+#endif
+#ifndef OCEAN_COL_CS_EXTRA
+#define OCEAN_COL_CS_EXTRA 12
+#endif
+    static constexpr int PS = OCEAN_COL_PAD_SHIFT;                      // LDS index padding (see padidx)
+    static constexpr int CS = LineFFT<N, PS>::LINE + OCEAN_COL_CS_EXTRA;   // LDS line stride (complex); measured best of a small sweep
     static constexpr int SY = N + 4;                                    // height exchange: column stride (floats)
     static constexpr int HR = (2 + WC - 1) / WC;                        // halo rounds (1 unless WC == 1)
 
@@ -1049,7 +1062,7 @@ namespace ocean
 
         OCEAN_STAMP(1);
 
-        fft_lines<N, 1>(v, ht, lines + hc * C::CS, C::CS, midtab, hw, halo);
+        fft_lines<N, 1, C::PS>(v, ht, lines + hc * C::CS, C::CS, midtab, hw, halo);
 
         OCEAN_STAMP(2);
 
@@ -1112,7 +1125,7 @@ namespace ocean
           int const hx = (hc == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
           float const hsigma = ((hx + elem_out<N>(ht, 0)) & 1) ? -1.0f : 1.0f;
 
-          fft_pair<N>(v[0], t, lines + cp * C::CS, w, true, vh[0], ht, lines + (W + hc) * C::CS, hw, halo, midtab);
+          fft_pair<N, C::PS>(v[0], t, lines + cp * C::CS, w, true, vh[0], ht, lines + (W + hc) * C::CS, hw, halo, midtab);
 
           if (halo)
           {
@@ -1122,10 +1135,10 @@ namespace ocean
           }
         }
         else
-          fft_lines<N, CPT>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
+          fft_lines<N, CPT, C::PS>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
       }
       else
-        fft_lines<N, CPT>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
+        fft_lines<N, CPT, C::PS>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
 #endif
       OCEAN_STAMP(4 + 2 * field);
 

@@ -21,7 +21,7 @@ static void run_line(float const *in, float *out)
     tw[k] = cf{ (float)std::cos(a), (float)std::sin(a) };
   }
 
-  std::vector<cf> line(P::LINE);
+  std::vector<cf> line(L::LINE);
   std::vector<cf> regs(N);   // [t][s]
   std::vector<typename L::Twiddles> w(P::T);
   std::vector<cf> midtab(L::MIDTAB + 1);
