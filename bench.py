@@ -44,6 +44,19 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/):
+    bench.py cannot run the profiler on itself, so the value is the latest committed measurement for exactly this
+    kernel and workload, or None."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if j.get("workload") == workload and kernel in j["kernels"]:
+            return j["kernels"][kernel]["traffic_bytes"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB)"
+    except Exception:
+        pass
+    return None, None
+
+
 def cpu_baseline(N, cascades, states, budget):
     """The oracle (oracle/ocean_oracle.cpp, OpenMP over rows / columns) timed on this host on a bounded sample of
     the same workload.  A reported baseline, not a target.  kind = "port": the reference itself cannot be built or
@@ -170,6 +183,9 @@ def main():
         ach = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
         step_ach = (row_b + col_b) / ((row_ms + col_ms) * 1e-3) / 1e9 if row_ms + col_ms > 0 else 0.0
 
+        kernel_name = f"ocean_{dom[0]}_kernel<{N}>"
+        traffic, traffic_source = measured_traffic(kernel_name, f"{N}x{N} x {C} cascades")
+
         line = {
             "metric": "ocean grids/sec (N x N displacement step)",
             "value": grids / elapsed,
@@ -194,12 +210,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"ocean_{dom[0]}_kernel<{N}>",
+                "kernel": kernel_name,
                 "achieved": ach,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "bytes_per_launch": dom[2],
                 "ms_per_launch": dom[1],
                 "rowpass": {"ms": row_ms, "bytes": row_b, "GBps": row_b / (row_ms * 1e-3) / 1e9 if row_ms > 0 else 0.0},

@@ -3,6 +3,7 @@
 # usage: tools/profile_gpu.sh <outdir-name> [bench args...]
 set -u
 out=gpurun_out/$1; shift
+rm -rf $out
 mkdir -p $out
 export TMPDIR=/tmp
 ARGS="--cpu-seconds 0 $*"   # bench.py defaults (200 steps, 10 warm-up, 1024x1024 x 4) without the CPU leg
