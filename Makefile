@@ -26,11 +26,18 @@ $(LIB): $(SRC) $(DEPS)
 oracle:
 	$(MAKE) -C oracle liboracle.so
 
+# CPU emulation of the thread-parallel line FFT (tests only)
+EMUL = tests/cpu/libfft_core_emul.so
+emul: $(EMUL)
+
+$(EMUL): tests/cpu/fft_core_emul.cpp datum_amd/csrc/ocean_fft_core.h
+	$(CXX) -O2 -std=c++14 -fPIC -shared -o $@ tests/cpu/fft_core_emul.cpp
+
 resource-usage: $(SRC) $(DEPS)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(SRC) 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" 
 
 clean:
-	rm -f $(LIB) $(HOSTLIB)
+	rm -f $(LIB) $(HOSTLIB) $(EMUL)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean resource-usage
+.PHONY: all oracle emul clean resource-usage

@@ -1,4 +1,5 @@
 import os
+import subprocess
 import sys
 
 import pytest
@@ -10,6 +11,25 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    """The shared libraries are build products (git-ignored; they travel to the GPU box with the snapshot).
+    On a fresh checkout build them once; hipcc cross-compiles gfx950 without a GPU."""
+    need = [
+        os.path.join(ROOT, "datum_amd", "lib", "libdatum_ocean_hip.so"),
+        os.path.join(ROOT, "datum_amd", "lib", "libdatum_ocean_host.so"),
+        os.path.join(ROOT, "oracle", "liboracle.so"),
+        os.path.join(ROOT, "tests", "cpu", "libfft_core_emul.so"),
+    ]
+    if all(os.path.exists(p) for p in need):
+        return
+    env = dict(os.environ)
+    env["PATH"] = "/opt/rocm/bin:" + env.get("PATH", "")
+    subprocess.check_call(["make", "-C", ROOT, "all", "emul"], env=env, stdout=subprocess.DEVNULL)
+
+
+_ensure_built()
 
 
 @pytest.fixture(scope="session")
