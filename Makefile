@@ -13,7 +13,7 @@ HOSTDEPS = datum_amd/host/ocean.h datum_amd/host/lml.h include/datum_ocean_hip.h
 CXX ?= g++
 HOSTFLAGS ?= -O2 -std=c++14 -fPIC -ffp-contract=off -fno-fast-math -Wall
 
-all: $(LIB) $(HOSTLIB) oracle
+all: $(LIB) $(HOSTLIB) oracle examples
 
 # the C++ host shim links only against the C ABI of the HIP module
 $(HOSTLIB): $(HOSTSRC) $(HOSTDEPS) $(LIB)
@@ -26,6 +26,13 @@ $(LIB): $(SRC) $(DEPS)
 oracle:
 	$(MAKE) -C oracle liboracle.so
 
+# datum's example-ocean flow against the host shim, headless
+EXAMPLE = examples/ocean_headless
+examples: $(EXAMPLE)
+
+$(EXAMPLE): examples/ocean_headless.cpp $(HOSTLIB)
+	$(CXX) -O2 -std=c++14 -Wall -o $@ examples/ocean_headless.cpp -Ldatum_amd/lib -ldatum_ocean_host -ldatum_ocean_hip -Wl,-rpath,'$$ORIGIN/../datum_amd/lib'
+
 # CPU emulation of the thread-parallel line FFT (tests only)
 EMUL = tests/cpu/libfft_core_emul.so
 emul: $(EMUL)
@@ -37,7 +44,7 @@ resource-usage: $(SRC) $(DEPS)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(SRC) 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" 
 
 clean:
-	rm -f $(LIB) $(HOSTLIB) $(EMUL)
+	rm -f $(LIB) $(HOSTLIB) $(EMUL) $(EXAMPLE)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle emul clean resource-usage
+.PHONY: all oracle emul examples clean resource-usage

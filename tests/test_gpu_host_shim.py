@@ -1,0 +1,105 @@
+"""GPU tests of the C++ host shim (datum_amd/host/ocean.h) driven the way datum's example-ocean drives the reference
+(examples/ocean/ocean.cpp): through the compiled example program and through the flat C view used by Python."""
+
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DT = np.float32(1.0 / 60.0)
+
+
+def rmse(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    return float(np.sqrt((d * d).mean()))
+
+
+def _oracle_run(oracle, N, seed, frames):
+    p = oracle.EXAMPLE
+    _, h0 = oracle.seed(N, seed, p["wavescale"], p["waveamplitude"], p["windspeed"], p["winddirection"], sanitize=True)
+    phase = np.zeros((N, N), np.float32)
+    sp, fl = 0.0, (0.0, 0.0)
+    for _ in range(frames):
+        oracle.update(phase, p["wavescale"], DT)
+        sp, fl = oracle.update_scalars(p["swellspeed"], p["swelllength"], p["windspeed"], p["winddirection"], DT, sp, fl)
+    maps = oracle.displace(h0, phase.copy(), p["wavescale"], p["choppiness"], w=oracle.weights(N, reduced=True))
+    s = oracle.example_oceanset(N, swellphase=sp)
+    return phase, sp, fl, maps, s
+
+
+@pytest.mark.parametrize("N,frames", [(64, 60), (256, 5)])
+def test_example_program(oracle, N, frames):
+    exe = os.path.join(ROOT, "examples", "ocean_headless")
+    assert os.path.exists(exe), "build it with `make examples`"
+    out = subprocess.run([exe, str(N), str(frames), "1000"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    vals = {}
+    for line in out.stdout.splitlines():
+        toks = line.split()
+        key, nums = None, []
+        for tok in toks:
+            try:
+                nums.append(float(tok))
+            except ValueError:
+                if key is not None and nums:
+                    vals[key] = nums
+                key, nums = tok, []
+        if key is not None and nums:
+            vals[key] = nums
+    phase, sp, fl, maps, s = _oracle_run(oracle, N, 1000, frames)
+    assert vals["swellphase"][0] == pytest.approx(sp, abs=1e-7)
+    assert vals["flow"] == pytest.approx(list(fl), rel=1e-6)
+    assert np.float32(vals["phase[10][20]"][0]) == phase[10, 20]  # bit-exact device phase, printed with 9 digits
+    assert np.float32(vals[f"phase[{N-1}][{N-1}]"][0]) == phase[N - 1, N - 1]
+    assert vals["dz_rms"][0] == pytest.approx(float(np.sqrt((maps[0, ..., 2].astype(np.float64) ** 2).mean())), rel=1e-5)
+    assert vals["map[0][5][7]"] == pytest.approx(list(maps[0, 5, 7, :3]), abs=5e-6)
+    assert vals["map[1][5][7]"] == pytest.approx(list(maps[1, 5, 7, :3]), abs=5e-6)
+    v = oracle.gen(s, maps, 64, 64)[40, 33]
+    got = vals["pos"] + vals["uv"] + vals["n"] + vals["t"]
+    assert np.allclose(got, v, rtol=2e-4, atol=2e-4)
+
+
+def test_render_through_host_api_and_wave_change(oracle):
+    # seed, tick, render; then change the wind (lerp_ocean_waves recomputes h0, ocean.cpp:185-213) and keep going:
+    # the device keeps its phase, takes the new h0, and still matches the oracle run the same way
+    from datum_amd import host_api
+
+    N = 128
+    e = oracle.EXAMPLE
+    p = host_api.OceanParams(N, **host_api.EXAMPLE_TUNABLES)
+    p.seed_ocean(1003)
+    phase = np.zeros((N, N), np.float32)
+    with host_api.OceanContext(N) as ctx:
+        mesh = ctx.create_ocean(32, 48)
+        for _ in range(7):
+            p.update_ocean(DT)
+            oracle.update(phase, e["wavescale"], DT)
+        ctx.render_ocean_surface(mesh, p)
+        m1 = ctx.read_displacement()
+        want1 = oracle.displace(p.height.copy(), phase.copy(), e["wavescale"], e["choppiness"], w=oracle.weights(N, reduced=True))
+        assert rmse(m1[..., :3], want1[..., :3]) < 1e-5
+
+        p.lerp_ocean_waves(30.0, 0.004, 12.0, (0.6, 0.8), 0.5)
+        s = p.scalars()
+        for _ in range(3):
+            p.update_ocean(DT)
+            oracle.update(phase, s.wavescale, DT)
+        ctx.render_ocean_surface(mesh, p)
+        ctx.fetch_ocean_state(p)
+        assert np.array_equal(p.phase, phase)
+        m2 = ctx.read_displacement()
+        want2 = oracle.displace(p.height.copy(), phase.copy(), s.wavescale, s.choppiness, w=oracle.weights(N, reduced=True))
+        assert rmse(m2[..., :3], want2[..., :3]) < 1e-5
+        assert rmse(m2[..., :3], m1[..., :3]) > 1e-3  # the sea really changed
+
+        verts = ctx.read_vertices(mesh)
+        so = oracle.OceanSet.from_buffer_copy(bytes(p.oceanset()))
+        vwant = oracle.gen(so, m2, 32, 48)
+        assert (np.abs(verts - vwant) / (1 + np.abs(vwant))).max() < 2e-4
+        idx = ctx.read_indices(mesh)
+        assert np.array_equal(idx, oracle.indices(32, 48))
