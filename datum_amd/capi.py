@@ -56,6 +56,9 @@ SYMBOLS = {
     "datum_ocean_set_cascade": (I, [P, I, F, F]),
     "datum_ocean_upload_state": (I, [P, I, P, P]),
     "datum_ocean_read_state": (I, [P, I, P]),
+    "datum_ocean_upload_seed": (I, [P, I, P]),
+    "datum_ocean_rebuild_height": (I, [P, I, F, F, F, F, F]),
+    "datum_ocean_read_height": (I, [P, I, P]),
     "datum_ocean_update": (I, [P, F]),
     "datum_ocean_displace": (I, [P]),
     "datum_ocean_gen": (I, [P, I, ctypes.POINTER(OceanSet), I, I, P]),
@@ -177,6 +180,19 @@ class Ocean:
             phase = np.ascontiguousarray(phase, np.float32)
             assert phase.size == self.N * self.N
         self._check(self.lib.datum_ocean_upload_state(self.h, cascade, _ptr(h0), _ptr(phase) if phase is not None else None))
+
+    def upload_seed(self, cascade, seed):
+        seed = np.ascontiguousarray(seed, np.float32)
+        assert seed.size == 2 * self.N * self.N
+        self._check(self.lib.datum_ocean_upload_seed(self.h, cascade, _ptr(seed)))
+
+    def rebuild_height(self, cascade, wavescale, waveamplitude, windspeed, winddirection):
+        self._check(self.lib.datum_ocean_rebuild_height(self.h, cascade, wavescale, waveamplitude, windspeed, winddirection[0], winddirection[1]))
+
+    def read_height(self, cascade):
+        out = np.empty((self.N, self.N, 2), np.float32)
+        self._check(self.lib.datum_ocean_read_height(self.h, cascade, _ptr(out)))
+        return out
 
     def read_state(self, cascade):
         out = np.empty((self.N, self.N), np.float32)

@@ -26,6 +26,7 @@ struct datum_ocean_ctx
   hipStream_t ownstream = nullptr;
 
   float2 *h0 = nullptr;
+  float2 *seed = nullptr;             // [cascade][N*N] OceanParams::seed, only when the caller uploads it
   float *phase = nullptr;
   cf *spec = nullptr;
   cf *halo = nullptr;                 // [cascade][tiles][2][N] tile-border columns of the row-transformed height
@@ -355,6 +356,7 @@ int datum_ocean_destroy(datum_ocean_t ctx)
     (void)hipEventDestroy(ctx->complete);
 
   (void)hipFree(ctx->h0);
+  (void)hipFree(ctx->seed);
   (void)hipFree(ctx->phase);
   (void)hipFree(ctx->spec);
   (void)hipFree(ctx->halo);
@@ -489,6 +491,84 @@ int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, fl
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));   // the host buffers are the caller's again
 
   ctx->uploaded[cascade] = true;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_upload_seed(datum_ocean_t ctx, int cascade, float const *seed)
+{
+  if (!ctx || !seed)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_upload_seed: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_upload_seed: cascade out of range");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  size_t const P = plane(ctx);
+
+  if (!ctx->seed)
+  {
+    HIPCHECK(ctx, hipMalloc(&ctx->seed, ctx->cascades * P * sizeof(float2)));
+    HIPCHECK(ctx, hipMemsetAsync(ctx->seed, 0, ctx->cascades * P * sizeof(float2), ctx->stream));
+  }
+
+  HIPCHECK(ctx, hipMemcpyAsync(ctx->seed + cascade * P, seed, P * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_rebuild_height(datum_ocean_t ctx, int cascade, float wavescale, float waveamplitude, float windspeed, float windx, float windy)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_rebuild_height: null handle");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_rebuild_height: cascade out of range");
+
+  if (!ctx->seed)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_rebuild_height: no seed on the device (datum_ocean_upload_seed)");
+
+  if (!(wavescale > 0))
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_rebuild_height: wavescale must be positive");
+
+  // queued updates belong to the old wave scale
+  int rc = datum_ocean_set_cascade(ctx, cascade, wavescale, ctx->casc[cascade].choppiness);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  size_t const P = plane(ctx);
+
+  hipLaunchKernelGGL(ocean_height_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->seed + cascade * P, ctx->h0 + cascade * P, ctx->N, wavescale, waveamplitude, windspeed, windx, windy);
+  HIPCHECK(ctx, hipGetLastError());
+
+  if (!ctx->uploaded[cascade])
+  {
+    HIPCHECK(ctx, hipMemsetAsync(ctx->phase + cascade * P, 0, P * sizeof(float), ctx->stream));
+    ctx->wildphase[cascade] = false;
+    ctx->uploaded[cascade] = true;
+  }
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_read_height(datum_ocean_t ctx, int cascade, float *h0)
+{
+  if (!ctx || !h0)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_read_height: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_read_height: cascade out of range");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  size_t const P = plane(ctx);
+
+  HIPCHECK(ctx, hipMemcpyAsync(h0, ctx->h0 + cascade * P, P * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
 
   return DATUM_OCEAN_OK;
 }

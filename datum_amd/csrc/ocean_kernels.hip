@@ -1208,6 +1208,48 @@ namespace ocean
     OCEAN_STAMP(10);
   }
 
+  //|---------------------- spectrum rebuild (lerp_ocean_waves) ----------------
+
+  // phillips(k, a, v, w) of ocean.cpp:89-107, same operation order
+  __device__ __forceinline__ float phillips_at(float kx, float ky, float a, float v, float wx, float wy)
+  {
+    if (kx == 0.0f && ky == 0.0f)
+      return 0.0f;
+
+    float kdotw = kx * wx + ky * wy;
+    float d = (kdotw < 0.0f) ? 0.2f : 1.0f;
+
+    float L = v * v / 9.81f;
+    float L2 = L * L;
+    float l2 = L2 * 0.001f * 0.001f;
+
+    float k2 = kx * kx + ky * ky;
+
+    return a * d * expf(-1.0f / (k2 * L2)) / (k2 * k2 * k2) * (kdotw * kdotw) * expf(-k2 * l2);
+  }
+
+  // h0 = seed * dk * sqrt(phillips / 2)   (ocean.cpp:196-209)
+  __global__ void ocean_height_kernel(float2 const *seed, float2 *h0, int N, float wavescale, float waveamplitude, float windspeed, float windx, float windy)
+  {
+    size_t const plane = (size_t)N * N;
+
+    float const dk = 6.2831855f / wavescale;
+
+    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x)
+    {
+      int m = (int)(i / N), n = (int)(i % N);
+
+      float y = dk * ((float)m - 0.5f * (float)N);
+      float x = dk * ((float)n - 0.5f * (float)N);
+
+      float amp = dk * sqrtf(phillips_at(x, y, waveamplitude, windspeed, windx, windy) / 2.0f);
+
+      float2 s = seed[i];
+
+      h0[i] = make_float2(s.x * amp, s.y * amp);
+    }
+  }
+
   //|---------------------- phase-only advance --------------------------------
   // used when more than MAX_PENDING updates are queued between two displace calls
 

@@ -100,6 +100,8 @@ extern "C"
     o.choppiness = s->choppiness; o.smoothing = s->smoothing;
   }
 
+  void datum_host_params_set_deviceheight(void *p, int on) { static_cast<OceanParams*>(p)->deviceheight = (on != 0); }
+
   float *datum_host_params_seed(void *p) { return static_cast<OceanParams*>(p)->seed.data(); }
   float *datum_host_params_height(void *p) { return static_cast<OceanParams*>(p)->height.data(); }
   float *datum_host_params_phase(void *p) { return static_cast<OceanParams*>(p)->phase.data(); }

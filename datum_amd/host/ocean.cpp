@@ -147,6 +147,20 @@ namespace
       context.boundstate = params.stateid;
       context.boundheight = params.heightid;
     }
+    else if (context.boundheight != params.heightid && params.deviceheight)
+    {
+      // lerp_ocean_waves changed the wave parameters: rebuild h0 on the device from the resident seed
+      if (context.boundseed != params.stateid)
+      {
+        check(context.hip, datum_ocean_upload_seed(context.hip, 0, params.seed.data()), "datum_ocean_upload_seed");
+
+        context.boundseed = params.stateid;
+      }
+
+      check(context.hip, datum_ocean_rebuild_height(context.hip, 0, params.wavescale, params.waveamplitude, params.windspeed, params.winddirection.x, params.winddirection.y), "datum_ocean_rebuild_height");
+
+      context.boundheight = params.heightid;
+    }
     else if (context.boundheight != params.heightid)
     {
       // lerp_ocean_waves changed h0 only: keep the device phase, which is ahead of params.phase
@@ -284,8 +298,11 @@ void lerp_ocean_waves(OceanParams &params, float wavescale, float waveamplitude,
   params.windspeed = lerp(params.windspeed, windspeed, t);
   params.winddirection = normalise(lerp(params.winddirection, winddirection, t));
 
-  // the spectrum envelope moved: new h0 from the stored seed (ocean.cpp:194-211)
-  rebuild_height(params);
+  // the spectrum envelope moved: new h0 from the stored seed (ocean.cpp:194-211), here or on the device
+  if (params.deviceheight)
+    params.heightid = g_stateids++;
+  else
+    rebuild_height(params);
 }
 
 
@@ -509,6 +526,9 @@ void fetch_ocean_state(OceanContext &context, OceanParams &params)
   bind_state(context, params);
 
   check(context.hip, datum_ocean_read_state(context.hip, 0, params.phase.data()), "datum_ocean_read_state");
+
+  if (params.deviceheight)
+    check(context.hip, datum_ocean_read_height(context.hip, 0, params.height.data()), "datum_ocean_read_height");
 }
 
 

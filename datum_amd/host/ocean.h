@@ -140,6 +140,7 @@ struct OceanContext
 
   std::uint64_t boundstate = 0;           // which OceanParams state is resident on the device
   std::uint64_t boundheight = 0;
+  std::uint64_t boundseed = 0;            // which OceanParams seed is resident on the device (deviceheight only)
 
   OceanContext() = default;
   OceanContext(OceanContext const &) = delete;
@@ -173,6 +174,11 @@ struct OceanParams
   std::vector<float> height;      // [N][N][2]   h0
   std::vector<float> phase;       // [N][N]      as of seed_ocean / the last fetch_ocean_state
   lml::Vec2 flow = { 0.0f, 0.0f };
+
+  // extension: let lerp_ocean_waves leave the h0 rebuild (ocean.cpp:194-211) to the device: the seed is uploaded once
+  // and render_ocean_surface runs the rebuild kernel when the wave parameters have changed.  `height` on the host is
+  // then stale until fetch_ocean_state().  Off by default (the reference recomputes on the host).
+  bool deviceheight = false;
 
   // device residency bookkeeping (not in the reference)
   std::uint64_t stateid = 0;            // changes when seed_ocean replaces the whole state
@@ -221,7 +227,7 @@ void render_ocean_surface(OceanContext &context, Ocean const *target, Camera con
 // displacement maps only (ocean.sim .. ocean.map), no mesh: what the bench times
 void displace_ocean_surface(OceanContext &context, OceanParams const &params);
 
-// copy the device-resident phase back into params.phase (applies any queued update first)
+// copy the device-resident phase (and, with deviceheight, h0) back into params (applies any queued update first)
 void fetch_ocean_state(OceanContext &context, OceanParams &params);
 
 // blocking read-backs for tools and tests

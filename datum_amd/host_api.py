@@ -63,6 +63,7 @@ def load():
             "datum_host_params_destroy": (None, [P]),
             "datum_host_params_get": (None, [P, ctypes.POINTER(Scalars)]),
             "datum_host_params_set": (None, [P, ctypes.POINTER(Scalars)]),
+            "datum_host_params_set_deviceheight": (None, [P, I]),
             "datum_host_params_seed": (ctypes.POINTER(F), [P]),
             "datum_host_params_height": (ctypes.POINTER(F), [P]),
             "datum_host_params_phase": (ctypes.POINTER(F), [P]),
@@ -138,6 +139,10 @@ class OceanParams:
     @property
     def phase(self):
         return self._arr(self.lib.datum_host_params_phase, (self.N, self.N))
+
+    def set_deviceheight(self, on=True):
+        """Extension: lerp_ocean_waves leaves the h0 rebuild to the device (datum_ocean_rebuild_height)."""
+        self.lib.datum_host_params_set_deviceheight(self.p, 1 if on else 0)
 
     def seed_ocean(self, rngseed=None):
         self.lib.datum_host_seed_ocean(self.p, 0 if rngseed is None else rngseed, 1 if rngseed is None else 0)

@@ -91,6 +91,15 @@ int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, flo
 int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, float const *phase);
 int datum_ocean_read_state(datum_ocean_t ctx, int cascade, float *phase);
 
+/* Device-side spectrum rebuild (what lerp_ocean_waves does on the host, ocean.cpp:194-211):
+ * keep OceanParams::seed (N*N*2 floats, ocean.cpp:140-141) resident and recompute
+ * h0 = seed * dk * sqrt(phillips(k, waveamplitude, windspeed, winddirection) / 2), dk = 2 pi / wavescale,
+ * on the device when the wind changes, instead of an O(N^2) host loop plus an 8*N*N-byte upload.
+ * rebuild_height also installs `wavescale` as the cascade's wave scale (choppiness is kept). */
+int datum_ocean_upload_seed(datum_ocean_t ctx, int cascade, float const *seed);
+int datum_ocean_rebuild_height(datum_ocean_t ctx, int cascade, float wavescale, float waveamplitude, float windspeed, float windx, float windy);
+int datum_ocean_read_height(datum_ocean_t ctx, int cascade, float *h0);
+
 /* -- the per-frame path ---------------------------------------------------------------------------------- */
 
 /* update_ocean's phase advance (ocean.cpp:223-233) for every cascade:
