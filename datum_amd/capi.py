@@ -73,7 +73,7 @@ SYMBOLS = {
     "datum_ocean_last_error": (ctypes.c_char_p, [P]),
     "datum_ocean_reference_weights": (I, [I, P]),
     "datum_ocean_debug_sim": (I, [P, I, P, P, P]),
-    "datum_ocean_debug_rowpass": (I, [P, I, P, P, P]),
+    "datum_ocean_debug_rowpass": (I, [P, I, P, P]),
     "datum_ocean_profile_begin": (I, [P, I, I]),
     "datum_ocean_profile_end": (I, [P, ctypes.POINTER(D), ctypes.POINTER(D), ctypes.POINTER(I)]),
     "datum_ocean_algorithmic_bytes": (I, [P, ctypes.POINTER(D), ctypes.POINTER(D)]),
@@ -222,9 +222,9 @@ class Ocean:
         return h, hx, hy
 
     def debug_rowpass(self, cascade):
-        h, hx, hy = (np.empty((self.N, self.N, 2), np.float32) for _ in range(3))
-        self._check(self.lib.datum_ocean_debug_rowpass(self.h, cascade, _ptr(h), _ptr(hx), _ptr(hy)))
-        return h, hx, hy
+        c, d = (np.empty((self.N, self.N, 2), np.float32) for _ in range(2))
+        self._check(self.lib.datum_ocean_debug_rowpass(self.h, cascade, _ptr(c), _ptr(d)))
+        return c, d
 
     def profile_begin(self, max_samples, stride=1):
         self._check(self.lib.datum_ocean_profile_begin(self.h, max_samples, stride))

@@ -22,6 +22,9 @@ struct datum_ocean_ctx
   int N = 0;
   int cascades = 0;
 
+  int cus = 0;                        // compute units of the device
+  int rowslots = 0;                   // row-pass workgroups resident at once (cus x occupancy)
+
   hipStream_t stream = nullptr;       // the one in use
   hipStream_t ownstream = nullptr;
 
@@ -98,6 +101,7 @@ namespace
     a.tw = ctx->tw;
     a.omega = ctx->omega;
     a.ndt = ndt;
+    a.cascades = ctx->cascades;
     for(int i = 0; i < MAX_PENDING; ++i)
       a.dt[i] = (i < ndt) ? dt[i] : 0.0f;
     memcpy(a.casc, ctx->casc, sizeof(a.casc));
@@ -105,9 +109,36 @@ namespace
   }
 
   template<int N>
-  hipError_t configure(char const **what)
+  hipError_t configure(datum_ocean_ctx *ctx, char const **what)
   {
     hipError_t e;
+
+#if OCEAN_PACKED
+    *what = "hipFuncSetAttribute(ocean_rowpack_kernel, MaxDynamicSharedMemorySize)";
+    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpack_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PackRowCfg<N>::LDS);
+    if (e != hipSuccess)
+      return e;
+
+    *what = "hipFuncSetAttribute(ocean_colpack_kernel, MaxDynamicSharedMemorySize)";
+    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpack_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PackColCfg<N>::LDS);
+    if (e != hipSuccess)
+      return e;
+#endif
+
+#if OCEAN_ROW_PAIRED
+    *what = "hipFuncSetAttribute(ocean_rowpair_kernel, MaxDynamicSharedMemorySize)";
+    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpair_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairCfg<N>::LDS);
+    if (e != hipSuccess)
+      return e;
+
+    int perCU = 0;
+    *what = "hipOccupancyMaxActiveBlocksPerMultiprocessor(ocean_rowpair_kernel)";
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, reinterpret_cast<void const*>(&ocean_rowpair_kernel<N>), PairCfg<N>::THREADS, PairCfg<N>::LDS);
+    if (e != hipSuccess)
+      return e;
+
+    ctx->rowslots = ctx->cus * (perCU < 1 ? 1 : perCU);
+#endif
 
     *what = "hipFuncSetAttribute(ocean_rowpass_kernel, MaxDynamicSharedMemorySize)";
     e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS);
@@ -121,8 +152,24 @@ namespace
   template<int N>
   hipError_t launch_rowpass(datum_ocean_ctx *ctx, StepArgs &a)
   {
-    dim3 grid(RowCfg<N>::BLOCKS, ctx->cascades);
     void *args[] = { &a };
+
+#if OCEAN_PACKED
+    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_rowpack_kernel<N>), dim3(PackRowCfg<N>::GROUPS, ctx->cascades), dim3(PackRowCfg<N>::THREADS), args, PackRowCfg<N>::LDS, ctx->stream);
+#endif
+
+#if OCEAN_ROW_PAIRED
+    // persistent: as many workgroups as fit at once, each walking an equal chunk of row pairs (fewer workgroups
+    // when that does not change the longest chunk)
+    int const total = ctx->cascades * PairCfg<N>::GROUPS;
+    int const slots = ctx->rowslots < total ? ctx->rowslots : total;
+    int const longest = (total + slots - 1) / slots;
+    int const blocks = (total + longest - 1) / longest;
+
+    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_rowpair_kernel<N>), dim3(blocks), dim3(PairCfg<N>::THREADS), args, PairCfg<N>::LDS, ctx->stream);
+#endif
+
+    dim3 grid(RowCfg<N>::BLOCKS, ctx->cascades);
 
     return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), grid, dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream);
   }
@@ -130,8 +177,13 @@ namespace
   template<int N>
   hipError_t launch_colpass(datum_ocean_ctx *ctx, StepArgs &a)
   {
-    dim3 grid(N / ColCfg<N>::W, ctx->cascades);
     void *args[] = { &a };
+
+#if OCEAN_PACKED
+    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_colpack_kernel<N>), dim3(PackColCfg<N>::TILES, ctx->cascades), dim3(PackColCfg<N>::THREADS), args, PackColCfg<N>::LDS, ctx->stream);
+#endif
+
+    dim3 grid(N / ColCfg<N>::W, ctx->cascades);
 
     return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), grid, dim3(ColCfg<N>::THREADS), args, ColCfg<N>::LDS, ctx->stream);
   }
@@ -266,6 +318,13 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
   ctx->N = resolution;
   ctx->cascades = cascades;
 
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1)
+      cus = 256;
+    ctx->cus = cus;
+  }
+
   size_t const P = plane(ctx);
 
   #define CREATECHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int rc_ = fail(nullptr, (int)e_, #call); datum_ocean_destroy(ctx); return rc_; } } while(0)
@@ -319,7 +378,7 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
   {
     hipError_t ce = hipSuccess;
     char const *what = "";
-    DISPATCH_N(resolution, ce = configure<NN>(&what));
+    DISPATCH_N(resolution, ce = configure<NN>(ctx, &what));
     if (ce != hipSuccess)
     {
       char buf[256];
@@ -865,9 +924,9 @@ int datum_ocean_debug_sim(datum_ocean_t ctx, int cascade, float *h, float *hx, f
   return DATUM_OCEAN_OK;
 }
 
-int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *h, float *hx, float *hy)
+int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *c, float *d)
 {
-  if (!ctx || !h || !hx || !hy)
+  if (!ctx || !c || !d)
     return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_debug_rowpass: null argument");
 
   if (cascade < 0 || cascade >= ctx->cascades)
@@ -881,15 +940,10 @@ int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *h, float *h
 
   size_t const P = plane(ctx);
 
-  float *dst[3] = { h, hx, hy };
-
-  for(int f = 0; f < 3; ++f)
-  {
-    hipLaunchKernelGGL(ocean_unblock_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->spec + ((size_t)cascade * 3 + f) * P, ctx->N, ctx->scratch + f * P);
-    HIPCHECK(ctx, hipGetLastError());
-    HIPCHECK(ctx, hipMemcpyAsync(dst[f], ctx->scratch + f * P, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
-  }
-
+  hipLaunchKernelGGL(ocean_unpack_kernel, dim3(1024), dim3(256), 0, ctx->stream, reinterpret_cast<cd const*>(ctx->spec) + (size_t)cascade * P, ctx->N, ctx->scratch, ctx->scratch + P);
+  HIPCHECK(ctx, hipGetLastError());
+  HIPCHECK(ctx, hipMemcpyAsync(c, ctx->scratch, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipMemcpyAsync(d, ctx->scratch + P, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
 
   return DATUM_OCEAN_OK;

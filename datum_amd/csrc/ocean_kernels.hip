@@ -47,6 +47,7 @@ namespace ocean
     float const *omega;  // [cascade][(N/2+1)^2] dispersion(k) by (|m - N/2|, |n - N/2|)
     cf *halo;            // [cascade][N/W tiles][2 sides][N] row-transformed h of the columns bordering each tile
     int ndt;
+    int cascades;
     float dt[MAX_PENDING];
     CascadeConst casc[DATUM_OCEAN_MAX_CASCADES];
 #ifdef OCEAN_STAMPS
@@ -867,6 +868,314 @@ namespace ocean
     }
   }
 
+  //|---------------------- row pass, mirror-paired and persistent ------------
+  // ocean.sim reads h0 at (y, x) and at the mirror index (N-1-y, N-1-x) (sim.comp:59).  Here a workgroup
+  // transforms row y and row N-1-y TOGETHER: the value one row needs from the other is then in a register of
+  // the thread holding the mirrored column, and the thread roles are laid out so that this partner is lane
+  // (L xor (2 HW - 1)) of the same wave -- one ds_bpermute per dword instead of a second trip to L2 per point.
+  // A workgroup walks a contiguous chunk of row pairs; the inputs of the next pair are requested as soon as the
+  // current pair's ocean.sim has consumed its own, so their latency is covered by the three-field transform.
+
+#ifndef OCEAN_ROW_PAIRED
+#define OCEAN_ROW_PAIRED 1
+#endif
+#ifndef OCEAN_PAIR_FIELDS
+#define OCEAN_PAIR_FIELDS 0          // lines per barrier phase: 1, 3, or 0 = by size
+#endif
+
+  template<int N>
+  struct PairCfg
+  {
+    static constexpr int E = Plan<N>::E;
+    static constexpr int T = Plan<N>::T;
+    static constexpr int HW = (T < 32) ? T : 32;                        // lanes of one row in a wave
+    static constexpr int PAIRS = (T >= 128) ? 1 : 128 / T;              // row pairs per workgroup
+    static constexpr int THREADS = 2 * T * PAIRS;
+    static constexpr int K = (OCEAN_PAIR_FIELDS != 0) ? OCEAN_PAIR_FIELDS : (N <= 1024 ? 3 : 1);
+    static constexpr int PS = 4;
+    static constexpr int LINE = LineFFT<N, PS>::LINE;
+    static constexpr int GROUPS = (N / 2) / PAIRS;                      // per cascade
+    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)PAIRS * 2 * K * LINE) * sizeof(cf);
+
+    static_assert(K == 1 || K == 3, "OCEAN_PAIR_FIELDS must be 1 or 3");
+    static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
+    static_assert(!QuadFFT<N>::ENABLED, "the paired row pass uses the generic line transform");
+  };
+
+  // opaque copies: what is derived from them is recomputed where it is used instead of being hoisted out of
+  // the persistent loop into (many) registers
+  __device__ __forceinline__ int launder_v(int x) { asm volatile("" : "+v"(x)); return x; }
+  __device__ __forceinline__ int launder_s(int x) { asm volatile("" : "+s"(x)); return x; }
+
+  template<int N>
+  struct PairInputs
+  {
+    float ph[Plan<N>::E];
+    float om[Plan<N>::E];
+    float2 hk[Plan<N>::E];
+  };
+
+  // group g of the launch -> cascade and first row pair
+  template<int N>
+  __device__ __forceinline__ void pair_request(PairInputs<N> &in, StepArgs const &a, int g, int pr, int half, int t, bool advance)
+  {
+    typedef PairCfg<N> C;
+    constexpr int E = Plan<N>::E;
+    constexpr int DX = elem_in<N>(0, 1) - elem_in<N>(0, 0);
+
+    size_t const plane = (size_t)N * N;
+
+    int const cascade = g / C::GROUPS;
+    int const yp = (g % C::GROUPS) * C::PAIRS + pr;
+    int const y = half ? N - 1 - yp : yp;
+
+    __amdgpu_buffer_rsrc_t rph = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
+    __amdgpu_buffer_rsrc_t rh0 = make_rsrc(a.h0 + cascade * plane, plane * sizeof(float2));
+
+    int const e0 = y * N + elem_in<N>(t, 0);
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+    {
+#ifdef OCEAN_ABLATE_ROWLOAD
+      int x = elem_in<N>(t, s);
+      in.ph[s] = 0.001f * (float)x;
+      in.hk[s] = make_float2(0.01f * (float)(x & 15), 0.02f);
+#else
+      in.ph[s] = buf_load_f32(rph, e0 * 4, DX * s * 4);
+      in.hk[s] = buf_load_f32x2(rh0, e0 * 8, DX * s * 8);
+#endif
+    }
+
+    if (advance)
+    {
+      float const *omega = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+#ifdef OCEAN_ABLATE_ROWLOAD
+        in.om[s] = 1.0f + 0.001f * (float)s;
+#else
+        in.om[s] = dispersion_lookup(omega, elem_in<N>(t, s), y, N);
+#endif
+    }
+  }
+
+  template<int N>
+  __global__ void __launch_bounds__(PairCfg<N>::THREADS) ocean_rowpair_kernel(StepArgs a)
+  {
+    typedef Plan<N> P;
+    typedef LineFFT<N> L;
+    typedef PairCfg<N> C;
+
+    constexpr int E = P::E;
+    constexpr int T = P::T;
+    constexpr int K = C::K;
+    constexpr int HW = C::HW;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    cf *midtab = reinterpret_cast<cf*>(smem);
+
+    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
+      midtab[i] = L::midtab_entry(a.tw, i);
+
+    // thread roles: pair pr of the workgroup; within it waves take HW columns-groups of row y in their lower
+    // lanes and the mirrored column groups of row N-1-y, in the same ascending order, in their upper lanes
+    int const pr0 = threadIdx.x / (2 * T);
+    int const u0 = threadIdx.x % (2 * T);
+    int const half0 = (u0 % (2 * HW)) / HW;
+    int const t0 = half0 ? T - 1 - (HW * (u0 / (2 * HW)) + (2 * HW - 1 - u0 % (2 * HW))) : HW * (u0 / (2 * HW)) + u0 % (2 * HW);
+
+    int const partner = (int)((threadIdx.x & 63) ^ (2 * HW - 1)) << 2;      // ds_bpermute address of the mirror thread
+
+    size_t const plane = (size_t)N * N;
+
+    constexpr int DXI = elem_in<N>(0, 1) - elem_in<N>(0, 0);                                            // row-major, inputs
+    constexpr int DBO = (int)(blocked<N>(0, elem_out<N>(0, 1)) - blocked<N>(0, elem_out<N>(0, 0)));     // blocked, outputs
+
+    static_assert(DXI % 8 == 0 && (elem_out<N>(0, 1) - elem_out<N>(0, 0)) % 8 == 0, "slots must be whole 8-column blocks apart");
+
+    bool const advance = a.ndt > 0;
+
+    typename LineTw<N>::type w;
+    LineTw<N>::load(a.tw, t0, w);
+
+    // this workgroup's chunk of (cascade, row pair group)s
+    int const total = a.cascades * C::GROUPS;
+    int g = (int)(((long long)blockIdx.x * total) / gridDim.x);
+    int const gend = (int)(((long long)(blockIdx.x + 1) * total) / gridDim.x);
+
+    if (g >= gend)
+      return;
+
+#ifdef OCEAN_STAMPS
+    unsigned long long *stampbase = a.stamps + (size_t)blockIdx.x * 32;
+    int const gfirst = g;
+#endif
+    OCEAN_STAMP(0);
+#ifdef OCEAN_STAMPS
+    { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); if (threadIdx.x == 0) stampbase[30] = rt_; }
+#endif
+
+    PairInputs<N> in;
+
+    pair_request<N>(in, a, g, pr0, half0, t0, advance);
+
+    order_fence();
+
+    auto pairstep = [&](int const g) __attribute__((always_inline))
+    {
+      int const t = launder_v(t0);
+      int const half = launder_v(half0);
+      int const pr = launder_v(pr0);
+
+      int const cascade = g / C::GROUPS;
+      int const yp = (g % C::GROUPS) * C::PAIRS + pr;
+      int const y = half ? N - 1 - yp : yp;
+
+      CascadeConst const cc = a.casc[cascade];
+
+      cf *line = midtab + L::MIDTAB + (pr * 2 + half) * K * C::LINE;
+
+      __amdgpu_buffer_rsrc_t rphase = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
+      __amdgpu_buffer_rsrc_t rspec = make_rsrc(a.spec + cascade * 3 * plane, 3 * plane * sizeof(cf));
+
+      float const ky = wavevector(y, N, cc.scale);
+
+#ifdef OCEAN_STAMPS
+      int const sb = 1 + 6 * (g - gfirst);
+#endif
+      OCEAN_STAMP(sb + 0);
+
+      // update_ocean (ocean.cpp:223-233), each pending dt in turn
+      if (advance)
+      {
+        for(int k = 0; k < a.ndt; ++k)
+        {
+          float const dt = a.dt[k];
+
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+            in.ph[s] = advance_phase_fast(in.ph[s], in.om[s] * dt);
+        }
+
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+        {
+#ifdef OCEAN_ABLATE_ROWSTORE
+          if (in.ph[s] == 123456.789f)
+#endif
+          buf_store_f32(in.ph[s], rphase, (y * N + elem_in<N>(t, 0)) * 4, DXI * s * 4);
+        }
+      }
+
+      OCEAN_STAMP(sb + 1);
+
+      // ocean.sim: the mirror value of slot s is slot E-1-s of the partner lane
+      cf h[E];
+      float kinv[E];
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+        float2 hm;
+        hm.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, in.hk[E - 1 - s].x)));
+        hm.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, in.hk[E - 1 - s].y)));
+
+        h[s] = sim_height(in.hk[s], hm, in.ph[s]);
+        kinv[s] = kinv_of(wavevector(elem_in<N>(t, s), N, cc.scale), ky);
+      }
+
+      OCEAN_STAMP(sb + 2);
+
+      order_fence();
+
+      int const gn = g + 1;
+
+      if (gn < gend)
+        pair_request<N>(in, a, gn, pr, half, t, advance);
+
+      order_fence();
+
+      // h, hx = -i h k^x, hy = -i h k^y (sim.comp:68-74), each through the row transform
+      if constexpr (K == 3)
+      {
+        cf v[K][E];
+
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+        {
+          float kx = wavevector(elem_in<N>(t, s), N, cc.scale) * kinv[s];
+          float kyn = ky * kinv[s];
+
+          v[0][s] = h[s];
+          v[1 % K][s] = cf{ h[s].y * kx, -h[s].x * kx };
+          v[2 % K][s] = cf{ h[s].y * kyn, -h[s].x * kyn };
+        }
+
+        OCEAN_STAMP(sb + 3);
+#ifndef OCEAN_ABLATE_ROWFFT
+        fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
+#endif
+        OCEAN_STAMP(sb + 4);
+
+        #pragma unroll
+        for(int field = 0; field < K; ++field)
+        {
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+          {
+#ifdef OCEAN_ABLATE_ROWSTORE
+            if (v[field][s].x == 123456.789f)
+#endif
+            buf_store_cf(v[field][s], rspec, (int)blocked<N>(y, elem_out<N>(t, 0)) * 8, (int)((field * plane + (size_t)DBO * s) * 8));
+          }
+        }
+      }
+      else
+      {
+        #pragma unroll
+        for(int field = 2; field >= 0; --field)
+        {
+          cf v[1][E];
+
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+          {
+            float kc = ((field == 1) ? wavevector(elem_in<N>(t, s), N, cc.scale) : ky) * kinv[s];
+
+            v[0][s] = (field == 0) ? h[s] : cf{ h[s].y * kc, -h[s].x * kc };
+          }
+
+          fft_lines<N, 1, C::PS>(v, t, line, C::LINE, midtab, w, true);
+
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+            buf_store_cf(v[0][s], rspec, (int)blocked<N>(y, elem_out<N>(t, 0)) * 8, (int)((field * plane + (size_t)DBO * s) * 8));
+        }
+      }
+
+      OCEAN_STAMP(sb + 5);
+
+      order_fence();
+    };
+
+    // The first pair is peeled off the loop: the loop is then entered with the same queue of outstanding
+    // requests as its back edge carries (next inputs, then this pair's stores), so the compiler's wait for the
+    // inputs counts the younger stores instead of draining them (a rolled loop drained every store per pair).
+    pairstep(g);
+
+    #pragma unroll 1
+    for(++g; g < gend; ++g)
+      pairstep(g);
+
+#ifdef OCEAN_STAMPS
+    { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); if (threadIdx.x == 0) stampbase[31] = rt_; }
+    OCEAN_STAMP(29);
+#endif
+  }
+
   //|---------------------- column pass + map ---------------------------------
 
   template<int N>
@@ -1206,6 +1515,416 @@ namespace ocean
     }
 
     OCEAN_STAMP(10);
+  }
+
+  //|---------------------- packed step: two complex transforms instead of three --
+  // ocean.map keeps only the REAL part of each of the three inverse transforms (map.comp:62-64).  The real part
+  // of the 2-D inverse transform of F is the transform of F's Hermitian part  F_H[k] = (F[k] + conj(F[-k])) / 2
+  // (-k = index negation modulo N), and two Hermitian spectra travel through one complex transform as A + i B:
+  //
+  //     C = h_H + i hx_H                        -> Re = height,          Im = choppy x
+  //     D = hy_H + i (-2 i sin(2 pi n / N)) h_H -> Re = choppy y,        Im = height[x-1] - height[x+1]
+  //
+  // (the second term of D is the transfer function of the central difference of map.comp:72-75, periodic wrap
+  // included: the x slope needs no neighbouring columns any more).  So the row pass transforms and writes two
+  // fields instead of three, the column pass reads and transforms two instead of three plus a halo, and one
+  // 16-byte value per point (C, D) crosses between them: 80 B/pt of HBM traffic instead of 96.
+  //
+  // The Hermitian part pairs index (y, x) with ((N-y) % N, (N-x) % N) -- not ocean.sim's own mirror (N-1-y, N-1-x)
+  // -- so a row-pass workgroup takes rows y and N-y together (rows 0 and N/2 pair with themselves and share a
+  // workgroup), evaluates ocean.sim once per point and swaps the values through LDS.
+  // k^ at the negated index is -k^, except where the index is its own negative (x = 0 or y = 0: the grid's k there
+  // is -pi N scale at both): the general form  F_H = (F[k] + conj(F[-k])) / 2  is evaluated with the sign that
+  // applies, so the result equals the reference's three transforms to rounding (tests/test_oracle_pins.py).
+
+#ifndef OCEAN_PACKED
+#define OCEAN_PACKED 1
+#endif
+
+  typedef float4 cd;    // (C.re, C.im, D.re, D.im) of one grid point
+
+  template<int N>
+  struct PackRowCfg
+  {
+    static constexpr int E = Plan<N>::E;
+    static constexpr int T = Plan<N>::T;
+    static constexpr int PAIRS = (T >= 128) ? 1 : 128 / T;              // row pairs per workgroup
+    static constexpr int THREADS = 2 * T * PAIRS;
+    static constexpr int K = 2;
+    static constexpr int PS = 4;
+    static constexpr int LINE = LineFFT<N, PS>::LINE;
+    static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
+    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)PAIRS * 2 * K * LINE) * sizeof(cf);
+
+    static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
+    static_assert(!QuadFFT<N>::ENABLED, "the packed row pass uses the generic line transform");
+  };
+
+  // sin(alpha + 2 pi s / E) for the E slots of a thread from (cos, sin)(alpha)
+  template<int E>
+  __device__ __forceinline__ float slot_sine(cf ca, int s)
+  {
+    constexpr float R = 0.70710678118654752440f;
+
+    if (E == 8)
+    {
+      switch(s & 7)
+      {
+        case 0: return ca.y;
+        case 1: return R * (ca.y + ca.x);
+        case 2: return ca.x;
+        case 3: return R * (ca.x - ca.y);
+        case 4: return -ca.y;
+        case 5: return -R * (ca.y + ca.x);
+        case 6: return -ca.x;
+        default: return R * (ca.y - ca.x);
+      }
+    }
+    else
+    {
+      switch(s & 3)
+      {
+        case 0: return ca.y;
+        case 1: return ca.x;
+        case 2: return -ca.y;
+        default: return -ca.x;
+      }
+    }
+  }
+
+  template<int N>
+  __global__ void __launch_bounds__(PackRowCfg<N>::THREADS) ocean_rowpack_kernel(StepArgs a)
+  {
+    typedef Plan<N> P;
+    typedef LineFFT<N> L;
+    typedef PackRowCfg<N> C;
+
+    constexpr int E = P::E;
+    constexpr int T = P::T;
+    constexpr int K = C::K;
+
+    static_assert(E == 8 || E == 4, "slot_sine covers E = 4 and 8");
+    static_assert(elem_in<N>(0, 1) == T && elem_out<N>(0, 1) == T, "slots are T columns apart");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    cf *midtab = reinterpret_cast<cf*>(smem);
+
+    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
+      midtab[i] = L::midtab_entry(a.tw, i);
+
+    // neighbouring pairs read each other's rows as ocean.sim's mirror rows: deal them to the same XCD
+    constexpr int G = C::GROUPS;
+    int const grp = (G % 8 == 0) ? (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+
+    int const cascade = blockIdx.y;
+
+    int const pr = threadIdx.x / (2 * T);
+    int const half = (threadIdx.x % (2 * T)) / T;
+    int const t = threadIdx.x % T;
+
+    int const p = grp * C::PAIRS + pr;                       // rows p and N - p; p = 0: rows 0 and N/2, each its own partner
+    int const y = half ? (p == 0 ? N / 2 : N - p) : p;
+    int const otherhalf = (p == 0) ? half : 1 - half;
+
+    cf *line = midtab + L::MIDTAB + (pr * 2 + half) * K * C::LINE;
+    cf *swap_out = line + C::LINE;
+    cf const *swap_in = midtab + L::MIDTAB + (pr * 2 + otherhalf) * K * C::LINE + C::LINE;
+
+    CascadeConst const cc = a.casc[cascade];
+
+    size_t const plane = (size_t)N * N;
+
+    float2 const *h0 = a.h0 + cascade * plane;
+    float const *omega = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
+
+    constexpr int DBO = (int)(blocked<N>(0, T) - blocked<N>(0, 0));
+
+    static_assert(T % 8 == 0, "slots must be whole 8-column blocks apart");
+
+    __amdgpu_buffer_rsrc_t rphase = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
+    __amdgpu_buffer_rsrc_t rh0 = make_rsrc(h0, plane * sizeof(float2));
+    __amdgpu_buffer_rsrc_t rspec = make_rsrc(reinterpret_cast<cd*>(a.spec) + cascade * plane, plane * sizeof(cd));
+
+    bool const advance = a.ndt > 0;
+
+    // inputs of ocean.sim: this row of phase and h0, the mirror row (sim.comp:59) backwards
+    float ph[E], om[E];
+    float2 hk[E], hm[E];
+
+    {
+      int const e0 = y * N + t;
+      int const m0 = (N - 1 - y) * N + (N - 1 - t - T * (E - 1));
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+#ifdef OCEAN_ABLATE_ROWLOAD
+        ph[s] = 0.001f * (float)(t + T * s);
+        hk[s] = make_float2(0.01f * (float)((t + s) & 15), 0.02f);
+        hm[s] = make_float2(0.03f, 0.01f * (float)(y & 15));
+#else
+        ph[s] = buf_load_f32(rphase, e0 * 4, T * s * 4);
+        hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
+        hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
+#endif
+      }
+
+      if (advance)
+      {
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+#ifdef OCEAN_ABLATE_ROWLOAD
+          om[s] = 1.0f + 0.001f * (float)s;
+#else
+          om[s] = dispersion_lookup(omega, t + T * s, y, N);
+#endif
+      }
+    }
+
+    cf const ca = a.tw[t];                  // exp(2 pi i t / N)
+
+    typename LineTw<N>::type w;
+    LineTw<N>::load(a.tw, t, w);
+
+    // update_ocean (ocean.cpp:223-233), each pending dt in turn
+    if (advance)
+    {
+      for(int k = 0; k < a.ndt; ++k)
+      {
+        float const dt = a.dt[k];
+
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+          ph[s] = advance_phase_fast(ph[s], om[s] * dt);
+      }
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+#ifdef OCEAN_ABLATE_ROWSTORE
+        if (ph[s] == 123456.789f)
+#endif
+        buf_store_f32(ph[s], rphase, (y * N + t) * 4, T * s * 4);
+      }
+    }
+
+    // ocean.sim once per point; the value goes to the thread that holds the negated index
+    cf h[E];
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+    {
+      h[s] = sim_height(hk[s], hm[s], ph[s]);
+
+      swap_out[padidx<C::PS>(t + T * s)] = h[s];
+    }
+
+    __syncthreads();
+
+    float const ky = wavevector(y, N, cc.scale);
+    float const sy = (y == 0) ? -1.0f : 1.0f;
+
+    cf v[K][E];
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+    {
+      int const x = t + T * s;
+
+      cf n = swap_in[padidx<C::PS>((N - x) & (N - 1))];
+
+      cf const b = cf{ n.x, -n.y };                                   // conj(h~[-k])
+
+      float const kx = wavevector(x, N, cc.scale);
+      float const kinv = kinv_of(kx, ky);
+      float const khx = kx * kinv, khy = ky * kinv;
+
+      // Hermitian parts of h~, and of h~ as it enters hx and hy (k^ does not change sign where the index is its own negative)
+      float const sx = (s == 0 && t == 0) ? -1.0f : 1.0f;
+
+      cf const hh = cf{ 0.5f * (h[s].x + b.x), 0.5f * (h[s].y + b.y) };
+      cf const hhx = (s == 0) ? cf{ 0.5f * (h[s].x + sx * b.x), 0.5f * (h[s].y + sx * b.y) } : hh;
+      cf const hhy = cf{ 0.5f * (h[s].x + sy * b.x), 0.5f * (h[s].y + sy * b.y) };
+
+      float const s2 = 2.0f * slot_sine<E>(ca, s);                    // 2 sin(2 pi x / N)
+
+      // C = h_H + i (-i k^x hhx) = h_H + k^x hhx ;  D = -i k^y hhy + 2 sin(theta) h_H
+      v[0][s] = cf{ hh.x + khx * hhx.x, hh.y + khx * hhx.y };
+      v[1][s] = cf{ khy * hhy.y + s2 * hh.x, s2 * hh.y - khy * hhy.x };
+    }
+
+    // every thread has fetched its partner values before pass 0 overwrites the lines
+    __syncthreads();
+
+#ifndef OCEAN_ABLATE_ROWFFT
+    fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
+#endif
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+    {
+#ifdef OCEAN_ABLATE_ROWSTORE
+      if (v[0][s].x == 123456.789f)
+#endif
+      buf_store_f32x4(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
+    }
+  }
+
+  template<int N>
+  struct PackColCfg
+  {
+    static constexpr int E = Plan<N>::E;
+    static constexpr int T = Plan<N>::T;
+    static constexpr int WRAW = ((T <= 128) ? 512 : 1024) / T;
+    static constexpr int W = WRAW > 8 ? 8 : WRAW;                       // columns per workgroup, one per thread group
+    static constexpr int THREADS = W * T;
+    static constexpr int K = 2;
+#ifndef OCEAN_COL_PAD_SHIFT
+#define OCEAN_COL_PAD_SHIFT 3
+#endif
+#ifndef OCEAN_COL_CS_EXTRA
+#define OCEAN_COL_CS_EXTRA 12
+#endif
+    static constexpr int PS = OCEAN_COL_PAD_SHIFT;
+    static constexpr int CS = LineFFT<N, PS>::LINE + OCEAN_COL_CS_EXTRA;   // LDS line stride (complex)
+    static constexpr int SY = N + 64 / W;                                  // height exchange: column stride (floats)
+    static constexpr int TILES = N / W;
+
+    static constexpr size_t OFF_MAIN = (size_t)LineFFT<N>::MIDTAB * sizeof(cf);
+    static constexpr size_t MAIN_FFT = (size_t)W * K * CS * sizeof(cf);
+    static constexpr size_t MAIN_DZ = (size_t)W * SY * sizeof(float);
+    static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
+
+    static_assert(N % W == 0 && 8 % W == 0, "a tile must sit inside one 8-column block");
+    static_assert(OFF_MAIN % 16 == 0, "LDS carve must stay 16-byte aligned");
+  };
+
+  template<int N>
+  __global__ void __launch_bounds__(PackColCfg<N>::THREADS) ocean_colpack_kernel(StepArgs a)
+  {
+    typedef Plan<N> P;
+    typedef LineFFT<N> L;
+    typedef PackColCfg<N> C;
+
+    constexpr int E = P::E;
+    constexpr int T = P::T;
+    constexpr int W = C::W;
+    constexpr int K = C::K;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    cf *midtab = reinterpret_cast<cf*>(smem);
+    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [W][K][CS]
+    float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [W][SY], after the transforms
+
+    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
+      midtab[i] = L::midtab_entry(a.tw, i);
+
+    // tiles narrower than an 8-column block share its cache lines with their neighbours: contiguous bands per XCD
+    constexpr int NT = C::TILES;
+    int const tile = (NT % 8 == 0) ? (int)(blockIdx.x & 7) * (NT / 8) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+
+    int const cascade = blockIdx.y;
+
+    CascadeConst const cc = a.casc[cascade];
+
+    size_t const plane = (size_t)N * N;
+
+    int const cp = threadIdx.x % W;
+    int const t = threadIdx.x / W;
+    int const x = tile * W + cp;
+
+    constexpr int DBI = (int)(blocked<N>(T, 0) - blocked<N>(0, 0));      // blocked spectrum, slot to slot (elements)
+
+    static_assert(T % 8 == 0, "slots must be whole 8-row blocks apart");
+
+    __amdgpu_buffer_rsrc_t rspec = make_rsrc(reinterpret_cast<cd const*>(a.spec) + cascade * plane, plane * sizeof(cd));
+    __amdgpu_buffer_rsrc_t rmaps = make_rsrc(a.maps + (size_t)cascade * 2 * plane, 2 * plane * sizeof(float4));
+
+    float4 q[E];
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+    {
+#ifdef OCEAN_ABLATE_COLLOAD
+      q[s] = make_float4(0.01f * (float)((t + s) & 31), 0.02f * (float)s, 0.03f, 0.01f * (float)cp);
+#else
+      q[s] = buf_load_f32x4(rspec, (int)blocked<N>(t, x) * 16, DBI * s * 16);
+#endif
+    }
+
+    typename LineTw<N>::type w;
+    LineTw<N>::load(a.tw, t, w);
+
+    cf v[K][E];
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+    {
+      v[0][s] = cf{ q[s].x, q[s].y };
+      v[1][s] = cf{ q[s].z, q[s].w };
+    }
+
+#ifndef OCEAN_ABLATE_COLFFT
+    fft_lines<N, K, C::PS>(v, t, lines + (K * cp) * C::CS, C::CS, midtab, w, true);
+#endif
+
+    // (-1)^(x+y) of map.comp:60; a thread's rows differ by even amounts
+    float const sig = ((x + t) & 1) ? -1.0f : 1.0f;
+    float const sigchop = sig * cc.choppiness;
+
+    // the transform lines are free after the last barrier of fft_lines: heights of this column for the y slope
+    float *own = dzmain + cp * C::SY;
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+      own[t + T * s] = v[0][s].x * sig;
+
+    __syncthreads();
+
+    float const nz = cc.nz;
+
+    int const o0 = (t * N + x) * 16;                 // byte offset of this thread's first texel
+
+    #pragma unroll
+    for(int s = 0; s < E; ++s)
+    {
+      int const y = t + T * s;
+
+      // displacement (map.comp:62-64) and central-difference normal (map.comp:72-77)
+      float const dz = v[0][s].x * sig;
+      float const dx = v[0][s].y * sigchop;
+      float const dy = v[1][s].x * sigchop;
+
+      float const nx = -(v[1][s].y * sig);
+      float const ny = own[(y + 1) & (N - 1)] - own[(y + N - 1) & (N - 1)];
+      float const inv = rsqrtf(nx * nx + ny * ny + nz * nz);
+
+#ifdef OCEAN_ABLATE_COLSTORE
+      if (nx * inv + dx + dy == 123456.789f)
+#endif
+      {
+        buf_store_f32x4(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * N * 16);
+        buf_store_f32x4(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, (int)(((size_t)T * s * N + plane) * 16));
+      }
+    }
+  }
+
+  // blocked packed spectrum -> two row-major complex planes (datum_ocean_debug_rowpass)
+  __global__ void ocean_unpack_kernel(cd const *spec, int N, cf *c, cf *d)
+  {
+    size_t const plane = (size_t)N * N;
+
+    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x)
+    {
+      int y = (int)(i / N), x = (int)(i % N);
+
+      cd v = spec[((size_t)((y >> 3) * (N / 8) + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7)];
+
+      c[i] = cf{ v.x, v.y };
+      d[i] = cf{ v.z, v.w };
+    }
   }
 
   //|---------------------- spectrum rebuild (lerp_ocean_waves) ----------------

@@ -160,16 +160,29 @@ def test_sim_stage(capi, oracle, N):
         assert np.abs(g - w).max() <= 2e-6 * np.abs(w).max()
 
 
+def packed_fields(fields):
+    """The two fields the module transforms instead of ocean.sim's three (include/datum_ocean_hip.h,
+    datum_ocean_debug_rowpass): Hermitian parts of h, hx, hy packed as C = h_H + i hx_H, D = hy_H + 2 sin(theta_x) h_H."""
+    N = fields[0].shape[0]
+    idx = (-np.arange(N)) % N
+    z = [f[..., 0].astype(np.float64) + 1j * f[..., 1] for f in fields]
+    herm = [0.5 * (f + np.conj(f[idx][:, idx])) for f in z]
+    s2 = 2 * np.sin(2 * np.pi * np.arange(N) / N)[None, :]
+    C = herm[0] + 1j * herm[1]
+    D = herm[2] + s2 * herm[0]
+    return [np.stack([f.real, f.imag], -1).astype(np.float32) for f in (C, D)]
+
+
 @pytest.mark.parametrize("N", [64, 128, 256, 512, 1024, 2048])
 def test_rowpass_stage(capi, oracle, N):
-    # state after ocean.fftx: row transform of the three fields
+    # state after the row pass: ocean.fftx applied to the two packed fields built from ocean.sim's three
     p = oracle.EXAMPLE
     h0 = make_state(oracle, N, 1002)
     phase = np.zeros((N, N), np.float32)
     for _ in range(3):
         oracle.update(phase, p["wavescale"], DT)
     scale = np.float32(1) / np.float32(p["wavescale"])
-    fields = oracle.sim(h0, phase, scale)
+    fields = packed_fields(oracle.sim(h0, phase, scale))
     w = oracle.weights(N, reduced=True)
     with capi.Ocean(N, 1) as oc:
         oc.set_cascade(0, p["wavescale"], p["choppiness"])
