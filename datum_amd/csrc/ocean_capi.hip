@@ -23,7 +23,6 @@ struct datum_ocean_ctx
   int cascades = 0;
 
   int cus = 0;                        // compute units of the device
-  int rowslots = 0;                   // row-pass workgroups resident at once (cus x occupancy)
 
   hipStream_t stream = nullptr;       // the one in use
   hipStream_t ownstream = nullptr;
@@ -31,8 +30,7 @@ struct datum_ocean_ctx
   float2 *h0 = nullptr;
   float2 *seed = nullptr;             // [cascade][N*N] OceanParams::seed, only when the caller uploads it
   float *phase = nullptr;
-  cf *spec = nullptr;
-  cf *halo = nullptr;                 // [cascade][tiles][2][N] tile-border columns of the row-transformed height
+  cd *spec = nullptr;
   float4 *maps = nullptr;             // the one in use
   float4 *ownmaps = nullptr;
   cf *tw = nullptr;
@@ -96,7 +94,6 @@ namespace
     a.h0 = ctx->h0;
     a.phase = ctx->phase;
     a.spec = ctx->spec;
-    a.halo = ctx->halo;
     a.maps = ctx->maps;
     a.tw = ctx->tw;
     a.omega = ctx->omega;
@@ -111,42 +108,17 @@ namespace
   template<int N>
   hipError_t configure(datum_ocean_ctx *ctx, char const **what)
   {
-    hipError_t e;
-
-#if OCEAN_PACKED
-    *what = "hipFuncSetAttribute(ocean_rowpack_kernel, MaxDynamicSharedMemorySize)";
-    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpack_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PackRowCfg<N>::LDS);
-    if (e != hipSuccess)
-      return e;
-
-    *what = "hipFuncSetAttribute(ocean_colpack_kernel, MaxDynamicSharedMemorySize)";
-    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpack_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PackColCfg<N>::LDS);
-    if (e != hipSuccess)
-      return e;
-#endif
-
-#if OCEAN_ROW_PAIRED
-    *what = "hipFuncSetAttribute(ocean_rowpair_kernel, MaxDynamicSharedMemorySize)";
-    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpair_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairCfg<N>::LDS);
-    if (e != hipSuccess)
-      return e;
-
-    int perCU = 0;
-    *what = "hipOccupancyMaxActiveBlocksPerMultiprocessor(ocean_rowpair_kernel)";
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, reinterpret_cast<void const*>(&ocean_rowpair_kernel<N>), PairCfg<N>::THREADS, PairCfg<N>::LDS);
-    if (e != hipSuccess)
-      return e;
-
-    ctx->rowslots = ctx->cus * (perCU < 1 ? 1 : perCU);
-#endif
-
     *what = "hipFuncSetAttribute(ocean_rowpass_kernel, MaxDynamicSharedMemorySize)";
-    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS);
     if (e != hipSuccess)
       return e;
 
     *what = "hipFuncSetAttribute(ocean_colpass_kernel, MaxDynamicSharedMemorySize)";
-    return hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
+    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
+    if (e != hipSuccess)
+      return e;
+
+    return hipSuccess;
   }
 
   template<int N>
@@ -154,24 +126,7 @@ namespace
   {
     void *args[] = { &a };
 
-#if OCEAN_PACKED
-    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_rowpack_kernel<N>), dim3(PackRowCfg<N>::GROUPS, ctx->cascades), dim3(PackRowCfg<N>::THREADS), args, PackRowCfg<N>::LDS, ctx->stream);
-#endif
-
-#if OCEAN_ROW_PAIRED
-    // persistent: as many workgroups as fit at once, each walking an equal chunk of row pairs (fewer workgroups
-    // when that does not change the longest chunk)
-    int const total = ctx->cascades * PairCfg<N>::GROUPS;
-    int const slots = ctx->rowslots < total ? ctx->rowslots : total;
-    int const longest = (total + slots - 1) / slots;
-    int const blocks = (total + longest - 1) / longest;
-
-    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_rowpair_kernel<N>), dim3(blocks), dim3(PairCfg<N>::THREADS), args, PairCfg<N>::LDS, ctx->stream);
-#endif
-
-    dim3 grid(RowCfg<N>::BLOCKS, ctx->cascades);
-
-    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), grid, dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream);
+    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), dim3(RowCfg<N>::GROUPS, ctx->cascades), dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream);
   }
 
   template<int N>
@@ -179,13 +134,7 @@ namespace
   {
     void *args[] = { &a };
 
-#if OCEAN_PACKED
-    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_colpack_kernel<N>), dim3(PackColCfg<N>::TILES, ctx->cascades), dim3(PackColCfg<N>::THREADS), args, PackColCfg<N>::LDS, ctx->stream);
-#endif
-
-    dim3 grid(N / ColCfg<N>::W, ctx->cascades);
-
-    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), grid, dim3(ColCfg<N>::THREADS), args, ColCfg<N>::LDS, ctx->stream);
+    return hipLaunchKernel(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), dim3(ColCfg<N>::TILES, ctx->cascades), dim3(ColCfg<N>::THREADS), args, ColCfg<N>::LDS, ctx->stream);
   }
 
   #define DISPATCH_N(n, expr) \
@@ -334,13 +283,8 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
 
   CREATECHECK(hipMalloc(&ctx->h0, cascades * P * sizeof(float2)));
   CREATECHECK(hipMalloc(&ctx->phase, cascades * P * sizeof(float)));
-  CREATECHECK(hipMalloc(&ctx->spec, cascades * 3 * P * sizeof(cf)));
+  CREATECHECK(hipMalloc(&ctx->spec, cascades * P * sizeof(cd)));
   CREATECHECK(hipMalloc(&ctx->ownmaps, cascades * 2 * P * sizeof(float4)));
-  {
-    size_t tiles = 0;
-    DISPATCH_N(resolution, tiles = TileCfg<NN>::TILES);
-    CREATECHECK(hipMalloc(&ctx->halo, (size_t)cascades * tiles * 2 * resolution * sizeof(cf)));
-  }
   CREATECHECK(hipMalloc(&ctx->tw, resolution * sizeof(cf)));
   CREATECHECK(hipMalloc(&ctx->omega, (size_t)cascades * (resolution / 2 + 1) * (resolution / 2 + 1) * sizeof(float)));
   CREATECHECK(hipMalloc(&ctx->wavescales, DATUM_OCEAN_MAX_CASCADES * sizeof(float)));
@@ -418,7 +362,6 @@ int datum_ocean_destroy(datum_ocean_t ctx)
   (void)hipFree(ctx->seed);
   (void)hipFree(ctx->phase);
   (void)hipFree(ctx->spec);
-  (void)hipFree(ctx->halo);
   (void)hipFree(ctx->ownmaps);
   (void)hipFree(ctx->tw);
   (void)hipFree(ctx->omega);
@@ -940,7 +883,7 @@ int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *c, float *d
 
   size_t const P = plane(ctx);
 
-  hipLaunchKernelGGL(ocean_unpack_kernel, dim3(1024), dim3(256), 0, ctx->stream, reinterpret_cast<cd const*>(ctx->spec) + (size_t)cascade * P, ctx->N, ctx->scratch, ctx->scratch + P);
+  hipLaunchKernelGGL(ocean_unpack_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->spec + (size_t)cascade * P, ctx->N, ctx->scratch, ctx->scratch + P);
   HIPCHECK(ctx, hipGetLastError());
   HIPCHECK(ctx, hipMemcpyAsync(c, ctx->scratch, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHECK(ctx, hipMemcpyAsync(d, ctx->scratch + P, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
@@ -1009,7 +952,9 @@ int datum_ocean_algorithmic_bytes(datum_ocean_t ctx, double *rowpass_bytes, doub
 
   double pts = (double)plane(ctx) * ctx->cascades;
 
-  // h0 8 + phase in 4 + phase out 4 + spectrum out 24 | spectrum in 24 + two RGBA32F layers 32
+  // the ALGORITHM's bytes as the reference states it, three transforms (bench.py's roofline):
+  // h0 8 + phase in 4 + phase out 4 + spectrum out 24 | spectrum in 24 + two RGBA32F layers 32.
+  // The packed step moves 16 instead of 24 spectrum bytes each way (32 + 48 = 80 B/pt of HBM traffic).
   if (rowpass_bytes) *rowpass_bytes = 40.0 * pts;
   if (colpass_bytes) *colpass_bytes = 56.0 * pts;
 

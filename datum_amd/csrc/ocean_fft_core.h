@@ -75,9 +75,31 @@ namespace ocean
 
     return __builtin_bit_cast(cf, r);
   }
+
+  // a + h*b and a - h*b for a real constant h (one packed FMA each)
+  __device__ __forceinline__ cf fma_real(cf a, cf b, float h)
+  {
+    v2f_ va = __builtin_bit_cast(v2f_, a), vb = __builtin_bit_cast(v2f_, b), vh = { h, h }, r;
+
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(vb), "v"(vh), "v"(va));
+
+    return __builtin_bit_cast(cf, r);
+  }
+
+  __device__ __forceinline__ cf fms_real(cf a, cf b, float h)
+  {
+    v2f_ va = __builtin_bit_cast(v2f_, a), vb = __builtin_bit_cast(v2f_, b), vh = { h, h }, r;
+
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(vb), "v"(vh), "v"(va));
+
+    return __builtin_bit_cast(cf, r);
+  }
 #else
   // a * b
   OC_HD cf cmul(cf a, cf b) { return { fmaf_(a.x, b.x, -(a.y * b.y)), fmaf_(a.x, b.y, a.y * b.x) }; }
+
+  OC_HD cf fma_real(cf a, cf b, float h) { return { fmaf_(h, b.x, a.x), fmaf_(h, b.y, a.y) }; }
+  OC_HD cf fms_real(cf a, cf b, float h) { return { fmaf_(-h, b.x, a.x), fmaf_(-h, b.y, a.y) }; }
 
   OC_HD cf add_muli(cf a, cf d) { return { a.x - d.y, a.y + d.x }; }
   OC_HD cf sub_muli(cf a, cf d) { return { a.x + d.y, a.y - d.x }; }
@@ -97,12 +119,6 @@ namespace ocean
 #ifndef OCEAN_FFT_E
 #define OCEAN_FFT_E 8
 #endif
-#ifndef OCEAN_QUAD_FFT
-#define OCEAN_QUAD_FFT 0      // measured on MI355X: correct, but 30 % more VALU instructions and 50 % slower (profiles/README.md)
-#endif
-
-  // N = 1024 runs as 32 x 32 with quad (DPP) butterflies and a single LDS exchange: see the end of this file
-  template<int N> struct QuadFFT { static constexpr bool ENABLED = (N == 1024) && (OCEAN_FFT_E == 8) && (OCEAN_QUAD_FFT != 0); };
 
   template<int N>
   struct Plan
@@ -115,8 +131,8 @@ namespace ocean
     static constexpr int RL = N / ipow(E, NP - 1);
     static constexpr int M = E / RL;
     static constexpr int NS_LAST = N / RL;      // product of the radices before the last pass
-    // LDS line length in complex elements for index padding i + (i >> PS) (no padding when swizzled instead)
-    template<int PS> static constexpr int line() { return QuadFFT<N>::ENABLED ? N : N + (N >> PS); }
+    // LDS line length in complex elements for index padding i + (i >> PS) 
+    template<int PS> static constexpr int line() { return N + (N >> PS); }
 
     static_assert(NP >= 2 && NP <= 6, "bad plan");
     static_assert(RL >= 2 && RL <= E && E % RL == 0, "bad plan");
@@ -171,15 +187,15 @@ namespace ocean
       idft4(v[0], v[2], v[4], v[6]);
       idft4(v[1], v[3], v[5], v[7]);
 
-      // t[1][c] *= exp(2 pi i c / 8)
-      cf t1 = { (v[3].x - v[3].y) * h, (v[3].x + v[3].y) * h };
-      cf t3 = { (-v[7].x - v[7].y) * h, (v[7].x - v[7].y) * h };
+      // t[1][c] *= exp(2 pi i c / 8):  t1 = h (1 + i) v3,  t3 = -h (1 - i) v7, the factor h folded into the sums
+      cf s1 = add_muli(v[3], v[3]);
+      cf s3 = sub_muli(v[7], v[7]);
 
       cf o[8];
       o[0] = v[0] + v[1];  o[4] = v[0] - v[1];
-      o[1] = v[2] + t1;    o[5] = v[2] - t1;
+      o[1] = fma_real(v[2], s1, h);   o[5] = fms_real(v[2], s1, h);
       o[2] = add_muli(v[4], v[5]);    o[6] = sub_muli(v[4], v[5]);
-      o[3] = v[6] + t3;    o[7] = v[6] - t3;
+      o[3] = fms_real(v[6], s3, h);   o[7] = fma_real(v[6], s3, h);
 
       OC_UNROLL
       for(int i = 0; i < 8; ++i)
@@ -309,7 +325,7 @@ namespace ocean
 
     // first middle pass (Ns = E) twiddles, shared by every line: midtab[r E + a] = exp(2 pi i a r / E^2),
     // a = t % E fastest so that a wave reads consecutive entries per r.  E*E entries (in LDS).
-    static constexpr int MIDTAB = (P::NP >= 3 && !QuadFFT<N>::ENABLED) ? E * E : 0;
+    static constexpr int MIDTAB = (P::NP >= 3) ? E * E : 0;
 
     static OC_HD cf midtab_entry(cf const *tw, int i)
     {
@@ -398,99 +414,7 @@ namespace ocean
     }
   };
 
-  //|---------------------- N = 1024 as 32 x 32 with quad butterflies --------
-  // Two radix-32 passes, ONE exchange through LDS (two barriers) instead of three exchanges (six barriers):
-  // a radix-32 butterfly is done by the four lanes of a quad, each holding 8 of the 32 points (point r = a + 4b in
-  // lane a, register b): radix-8 in registers over b, a twiddle exp(2 pi i q1 a / 32), then a radix-4 across the
-  // four lanes with two DPP quad_perm exchanges (no LDS, no barrier).  Lane L ends with outputs q = q1 + 8 br(L)
-  // in register q1, br = 2-bit reversal.
-  //
-  // Line ownership (T = 128 threads per line, thread t = 4 j + a):
-  //   before: slot b holds element  j + 32 a + 128 b          (quad_elem_in)
-  //   after:  slot q1 holds element j + 32 q1 + 256 br(a)     (quad_elem_out)
-
-  OC_HD constexpr int bitrev2(int a) { return ((a & 1) << 1) | ((a >> 1) & 1); }
-
-  OC_HD constexpr int quad_elem_in(int t, int s) { return (t >> 2) + 32 * (t & 3) + 128 * s; }
-  OC_HD constexpr int quad_elem_out(int t, int s) { return (t >> 2) + 32 * s + 256 * bitrev2(t & 3); }
-
   // element a thread holds in slot s before / after a line transform
-  template<int N> OC_HD constexpr int elem_in(int t, int s) { return QuadFFT<N>::ENABLED ? quad_elem_in(t, s) : t + Plan<N>::T * s; }
-  template<int N> OC_HD constexpr int elem_out(int t, int s) { return QuadFFT<N>::ENABLED ? quad_elem_out(t, s) : t + Plan<N>::T * s; }
-
-  // LDS position of line index i (10 bits) for the single exchange: an XOR swizzle under which both the pass-0
-  // stores (index 32 j + 8 k + q1 over a 16-lane group: 4 j x 4 k) and the pass-1 loads (index j + 32 a + 128 b over
-  // a 32-lane group: 8 j x 4 a) hit distinct banks.  P0 = b0^b3, P1 = b1^b4, P2 = b2^b6, P3 = b5, P4 = b6,
-  // P5 = b3, P6 = b4, P7.. = b7..  (a bijection: no padding, a line is exactly 1024 values)
-  OC_HD int quad_swizzle(int i)
-  {
-    int b3 = (i >> 3) & 1, b4 = (i >> 4) & 1, b5 = (i >> 5) & 1, b6 = (i >> 6) & 1;
-
-    return ((i & 7) ^ (b3 | (b4 << 1) | (b6 << 2))) | (b5 << 3) | (b6 << 4) | (b3 << 5) | (b4 << 6) | (i & ~127);
-  }
-
-  struct QuadTwiddles
-  {
-    cf c32[8];     // exp(2 pi i q1 a / 32), a = lane in quad              (inside a radix-32 butterfly)
-    cf pass1[8];   // exp(2 pi i j (a + 4 b) / 1024), j = t / 4            (between the two passes)
-  };
-
-  // tw[k] = exp(2 pi i k / 1024)
-  OC_HD void quad_load_twiddles(cf const *tw, int t, QuadTwiddles &w)
-  {
-    int a = t & 3, j = t >> 2;
-
-    OC_UNROLL
-    for(int q = 0; q < 8; ++q)
-    {
-      w.c32[q] = tw[(32 * q * a) & 1023];
-      w.pass1[q] = tw[(j * (a + 4 * q)) & 1023];
-    }
-  }
-
-  // the part of a radix-32 butterfly that stays inside a lane: radix-8 over b, then the lane's twiddles
-  OC_HD void quad_radix32_local(cf (&u)[8], QuadTwiddles const &w)
-  {
-    Radix<8>::run(u);
-
-    OC_UNROLL
-    for(int q = 1; q < 8; ++q)
-      u[q] = cmul(u[q], w.c32[q]);
-  }
-
-  // one radix-2 step across lanes: own*sign + partner (sign = +1 in the lower lane of the pair, -1 in the upper)
-  OC_HD cf quad_pair(cf own, cf partner, float sign) { return cf{ fmaf_(own.x, sign, partner.x), fmaf_(own.y, sign, partner.y) }; }
-
-#if defined(__HIPCC__)
-  // value of the lane whose quad index differs in bit 1 (XOR2: quad_perm [2,3,0,1]) or bit 0 (XOR1: [1,0,3,2])
-  template<int CTRL>
-  __device__ __forceinline__ float quad_xchg(float v)
-  {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-#else
-    return v;   // host pass of hipcc only parses this
-#endif
-  }
-
-  // the cross-lane radix-4 over the quad (inverse transform: w4 = +i); lane L ends with output q2 = br(L)
-  __device__ __forceinline__ void quad_radix4_lanes(cf (&u)[8], int a)
-  {
-    float const s1 = (a & 2) ? -1.0f : 1.0f;
-    float const s2 = (a & 1) ? -1.0f : 1.0f;
-    bool const rot = (a == 3);
-
-    OC_UNROLL
-    for(int q = 0; q < 8; ++q)
-    {
-      cf p = cf{ quad_xchg<0x4E>(u[q].x), quad_xchg<0x4E>(u[q].y) };
-      cf e = quad_pair(u[q], p, s1);                 // lanes 0,1: Y_a + Y_(a+2); lanes 2,3: Y_(a-2) - Y_a
-
-      e = rot ? cf{ -e.y, e.x } : e;                 // lane 3 holds Y1 - Y3: times i
-
-      cf r = cf{ quad_xchg<0xB1>(e.x), quad_xchg<0xB1>(e.y) };
-      u[q] = quad_pair(e, r, s2);                    // even lane: sum, odd lane: difference
-    }
-  }
-#endif
+  template<int N> OC_HD constexpr int elem_in(int t, int s) { return t + Plan<N>::T * s; }
+  template<int N> OC_HD constexpr int elem_out(int t, int s) { return t + Plan<N>::T * s; }
 }

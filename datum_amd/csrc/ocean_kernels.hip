@@ -4,17 +4,19 @@
 // :769-793) is done here in two fused kernels (+ gen):
 //
 //   row pass    update_ocean phase advance (ocean.cpp:223-233) + ocean.sim (data/ocean.sim.comp:44-79)
-//               + ocean.fftx (data/ocean.fftx.comp:49-100), N/8 threads per row, a few rows per workgroup
-//               reads  h0 (8 B/pt, plus its mirror row through L2), phase (4)   writes phase (4), spectrum (24)
+//               + ocean.fftx (data/ocean.fftx.comp:49-100) of TWO packed fields (see "packed step" below),
+//               N/8 threads per row, rows y and N-y per workgroup
+//               reads  h0 (8 B/pt, plus its mirror row through L2), phase (4)   writes phase (4), spectrum (16)
 //   column pass ocean.ffty (data/ocean.ffty.comp:49-100) + ocean.map (data/ocean.map.comp:51-82),
-//               one workgroup per tile of W columns, two adjacent columns per thread (16-byte loads / stores)
-//               reads spectrum (24)    writes 2 x RGBA32F (32)
+//               one workgroup per tile of W columns, one column per thread group
+//               reads spectrum (16)    writes 2 x RGBA32F (32)
 //
-// = 96 algorithmic bytes per grid point against the reference's 196.
+// = 80 bytes of HBM traffic per grid point; the algorithm as the reference states it (three transforms) has
+// 96 algorithmic bytes per point (the figure bench.py's roofline uses) and the reference as
+// written moves 196.
 //
-// Work spectrum layout (private to these kernels): per cascade and field, 8 x 8 blocks of complex
-// values, [y/8][x/8][y%8][x%8].  A row-pass workgroup (8 rows) writes one fully contiguous
-// 8*N*8-byte run per field; a column-pass wave reads one 512-byte block per load instruction.
+// Work spectrum layout (private to these kernels): per cascade, 8 x 8 blocks of 16-byte values (C, D),
+// [y/8][x/8][y%8][x%8]: a row of a block is one 128-byte line; a column-pass wave reads whole blocks.
 //
 // Built with -ffp-contract=off: products and sums are rounded as written (the phase state is
 // bit-identical to the host formula); the FFT butterflies ask for their FMAs explicitly.
@@ -29,6 +31,8 @@ namespace ocean
 {
   constexpr int MAX_PENDING = 8;
 
+  typedef float4 cd;    // (C.re, C.im, D.re, D.im) of one grid point: the two packed fields of the work spectrum
+
   struct CascadeConst
   {
     float wavescale;     // OceanParams::wavescale                 (update_ocean, ocean.cpp:225-229)
@@ -41,24 +45,28 @@ namespace ocean
   {
     float2 const *h0;    // [cascade][N*N]       OceanSet::h0
     float *phase;        // [cascade][N*N]       OceanSet::phase
-    cf *spec;            // [cascade][3][N*N]    Spectrum::h, hx, hy (blocked layout)
+    cd *spec;            // [cascade][N*N]       work spectrum (replaces Spectrum::h, hx, hy), blocked layout
     float4 *maps;        // [cascade][2][N*N]    displacementmap, 2 layers RGBA32F
     cf const *tw;        // [N]                  exp(+2 pi i k / N)
     float const *omega;  // [cascade][(N/2+1)^2] dispersion(k) by (|m - N/2|, |n - N/2|)
-    cf *halo;            // [cascade][N/W tiles][2 sides][N] row-transformed h of the columns bordering each tile
     int ndt;
     int cascades;
     float dt[MAX_PENDING];
     CascadeConst casc[DATUM_OCEAN_MAX_CASCADES];
 #ifdef OCEAN_STAMPS
-    unsigned long long *stamps;   // diagnostic builds only (tools/dbg/stamps.hip): [kernel][workgroup][16] s_memtime values
+    unsigned long long *stamps;   // diagnostic builds only (tools/dbg/stamps.hip): [kernel][workgroup][16] timestamps
 #endif
   };
 
 #ifdef OCEAN_STAMPS
-  #define OCEAN_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) stampbase[slot] = t_; } while(0)
+  // diagnostic builds only: s_memrealtime (100 MHz, one clock for the whole device) per phase, plus where the workgroup ran
+  #define OCEAN_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) stampbase[slot] = t_; } while(0)
+  #define OCEAN_STAMP_WHERE() do { unsigned int hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xcc_)); if (threadIdx.x == 0) { stampbase[14] = xcc_; stampbase[15] = hw_; } } while(0)
+  #define OCEAN_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
   #define OCEAN_STAMP(slot) do { } while(0)
+  #define OCEAN_STAMP_WHERE() do { } while(0)
+  #define OCEAN_WAIT_LOADS() do { } while(0)
 #endif
 
   template<int N>
@@ -223,6 +231,28 @@ namespace ocean
     return h;
   }
 
+  // the same value as  h0(k) e^{i phase} + conj(h0(mirror) e^{i phase})  (two complex products and a conjugating
+  // add: 5 packed instructions; equal to the expanded form above up to rounding)
+  __device__ __forceinline__ cf sim_height_products(float2 h0k, float2 h0mk, float phase)
+  {
+    float sin_v, cos_v;
+    sincos_phase(phase, &sin_v, &cos_v);
+
+    cf const e = cf{ cos_v, sin_v };
+    cf const u = cmul(cf{ h0k.x, h0k.y }, e);
+    cf const m = cmul(cf{ h0mk.x, h0mk.y }, e);
+
+    return cf{ u.x + m.x, u.y - m.y };
+  }
+
+  // 1 / |k| with the bare hardware reciprocal square root (1 ulp; k2 is never denormal on these grids), 0 at k = 0
+  __device__ __forceinline__ float kinv_fast(float kx, float ky)
+  {
+    float k2 = kx * kx + ky * ky;
+
+    return (k2 != 0.0f) ? __builtin_amdgcn_rsqf(k2) : 0.0f;
+  }
+
   // k of sim.comp:52 and its normalisation (sim.comp:54)
   __device__ __forceinline__ float wavevector(int i, int N, float scale)
   {
@@ -260,64 +290,11 @@ namespace ocean
 
   //|---------------------- per-thread twiddles of a line transform ------------
 
-  template<int N, bool QUAD = QuadFFT<N>::ENABLED> struct LineTw;
-
-  template<int N> struct LineTw<N, false>
+  template<int N> struct LineTw
   {
     typedef typename LineFFT<N>::Twiddles type;
     static __device__ __forceinline__ void load(cf const *tw, int t, type &w) { LineFFT<N>::load_twiddles(tw, t, w); }
   };
-
-  template<int N> struct LineTw<N, true>
-  {
-    typedef QuadTwiddles type;
-    static __device__ __forceinline__ void load(cf const *tw, int t, type &w) { quad_load_twiddles(tw, t, w); }
-  };
-
-  // N = 1024: two radix-32 passes on quads, one exchange (ocean_fft_core.h).  Every quad of an active wave
-  // must be fully active (DPP): `active` is uniform per wave at every call site.
-  template<int K>
-  __device__ __forceinline__ void fft_lines_quad(cf (&v)[K][8], int t, cf *line, int linestride, QuadTwiddles const &w, bool active)
-  {
-    int const a = t & 3;
-    int const j = t >> 2;
-
-    if (active)
-    {
-      int const base = quad_swizzle(32 * j + 8 * bitrev2(a));
-
-      #pragma unroll
-      for(int k = 0; k < K; ++k)
-      {
-        quad_radix32_local(v[k], w);
-        quad_radix4_lanes(v[k], a);
-
-        #pragma unroll
-        for(int q = 0; q < 8; ++q)
-          line[k * linestride + (base ^ q)] = v[k][q];
-      }
-    }
-
-    __syncthreads();
-
-    if (active)
-    {
-      int const base = quad_swizzle(j + 32 * a);
-
-      #pragma unroll
-      for(int k = 0; k < K; ++k)
-      {
-        #pragma unroll
-        for(int b = 0; b < 8; ++b)
-          v[k][b] = cmul(line[k * linestride + base + 128 * b], w.pass1[b]);
-
-        quad_radix32_local(v[k], w);
-        quad_radix4_lanes(v[k], a);
-      }
-    }
-
-    __syncthreads();
-  }
 
   //|---------------------- line FFTs with workgroup barriers ------------------
   // K independent lines per thread go through the exchange phases together, so the number of barriers per
@@ -327,14 +304,6 @@ namespace ocean
   __device__ __forceinline__ void fft_lines(cf (&v)[K][Plan<N>::E], int t, cf *line, int linestride, cf const *midtab, typename LineTw<N>::type const &w, bool active)
   {
     typedef LineFFT<N, PS> L;
-
-    if constexpr (QuadFFT<N>::ENABLED)
-    {
-      fft_lines_quad<K>(v, t, line, linestride, w, active);
-      return;
-    }
-    else
-    {
 
     if (active)
     {
@@ -437,1084 +406,6 @@ namespace ocean
     }
 
     __syncthreads();
-    }
-  }
-
-  // two independent line transforms, each with its own thread role, line and twiddles, through ONE set of
-  // barriers (generic path only): lets the column pass transform its halo columns together with field 0
-  template<int N, int PS>
-  __device__ __forceinline__ void fft_pair(cf (&va)[Plan<N>::E], int ta, cf *linea, typename LineFFT<N>::Twiddles const &wa, bool acta,
-                                           cf (&vb)[Plan<N>::E], int tb, cf *lineb, typename LineFFT<N>::Twiddles const &wb, bool actb,
-                                           cf const *midtab)
-  {
-    typedef LineFFT<N, PS> L;
-
-    if (acta) L::pass0(va, ta, linea);
-    if (actb) L::pass0(vb, tb, lineb);
-
-    __syncthreads();
-
-    if (Plan<N>::NP >= 3)
-    {
-      if (acta) L::template mid_load<1>(va, ta, linea, midtab, wa);
-      if (actb) L::template mid_load<1>(vb, tb, lineb, midtab, wb);
-      __syncthreads();
-      if (acta) L::template mid_store<1>(va, ta, linea);
-      if (actb) L::template mid_store<1>(vb, tb, lineb);
-      __syncthreads();
-    }
-
-    if (Plan<N>::NP >= 4)
-    {
-      if (acta) L::template mid_load<2>(va, ta, linea, midtab, wa);
-      if (actb) L::template mid_load<2>(vb, tb, lineb, midtab, wb);
-      __syncthreads();
-      if (acta) L::template mid_store<2>(va, ta, linea);
-      if (actb) L::template mid_store<2>(vb, tb, lineb);
-      __syncthreads();
-    }
-
-    if (Plan<N>::NP >= 5)
-    {
-      if (acta) L::template mid_load<3>(va, ta, linea, midtab, wa);
-      if (actb) L::template mid_load<3>(vb, tb, lineb, midtab, wb);
-      __syncthreads();
-      if (acta) L::template mid_store<3>(va, ta, linea);
-      if (actb) L::template mid_store<3>(vb, tb, lineb);
-      __syncthreads();
-    }
-
-    if (Plan<N>::NP >= 6)
-    {
-      if (acta) L::template mid_load<4>(va, ta, linea, midtab, wa);
-      if (actb) L::template mid_load<4>(vb, tb, lineb, midtab, wb);
-      __syncthreads();
-      if (acta) L::template mid_store<4>(va, ta, linea);
-      if (actb) L::template mid_store<4>(vb, tb, lineb);
-      __syncthreads();
-    }
-
-    if (acta) L::last(va, ta, linea, wa);
-    if (actb) L::last(vb, tb, lineb, wb);
-
-    __syncthreads();
-  }
-
-  //|---------------------- tile geometry shared by both passes ----------------
-
-#ifndef OCEAN_COL_THREADS
-#define OCEAN_COL_THREADS 512
-#endif
-#ifndef OCEAN_COL_CPT
-#define OCEAN_COL_CPT 0             // adjacent columns per thread: 1, 2 (16-byte accesses), or 0 = by size
-#endif
-
-#ifndef OCEAN_HALO_BUFFER
-#define OCEAN_HALO_BUFFER 0
-#endif
-
-  // a column-pass tile is W columns wide; the central differences of ocean.map need the height of the two
-  // columns next to it (periodic).  Reading those out of the blocked spectrum touches a whole 64-byte run per
-  // 8-byte value (measured: 168 MB fetched for 109 MB needed at 1024^2 x 4).  Two remedies:
-  //   OCEAN_HALO_BUFFER = 0: tiles are dealt to XCDs in contiguous bands (tile_of_block), so the runs a halo
-  //     column touches are the ones the neighbouring tile's workgroup, on the same XCD at about the same time,
-  //     loads anyway: the second toucher hits L2.
-  //   OCEAN_HALO_BUFFER = 1: the row pass also writes them, column-major, into a small halo array
-  //     halo[tile][0][y] = column tile*W - 1, halo[tile][1][y] = column tile*W + W (costs the row pass
-  //     scattered 8-byte stores).
-  template<int N>
-  struct TileCfg
-  {
-    static constexpr int T = Plan<N>::T;
-    static constexpr int WC = (OCEAN_COL_THREADS / T) < 1 ? 1 : (OCEAN_COL_THREADS / T) > 8 ? 8 : (OCEAN_COL_THREADS / T);
-
-    // one column per thread keeps the column pass near 110 VGPRs = two 512-thread workgroups per CU (measured
-    // 53 us against 59 us for two columns per thread at 1024^2 x 4); from N = 2048 up a workgroup would then span
-    // only 1-2 columns and the halo columns would dominate, so two columns per thread there
-    static constexpr int CPT = (OCEAN_COL_CPT != 0) ? OCEAN_COL_CPT : (T <= 128 ? 1 : 2);
-    static constexpr int W = CPT * WC;
-    static constexpr int TILES = N / W;
-
-    static_assert(N % W == 0 && T % W == 0, "tile width must divide the thread stride of a row");
-  };
-
-  //|---------------------- row pass ------------------------------------------
-
-#ifndef OCEAN_ROW_THREADS
-#define OCEAN_ROW_THREADS 256
-#endif
-#ifndef OCEAN_ROW_MINWAVES
-#define OCEAN_ROW_MINWAVES 1
-#endif
-#ifndef OCEAN_ROW_FIELDS
-#define OCEAN_ROW_FIELDS 3          // fields per barrier phase: 1 or 3
-#endif
-#ifndef OCEAN_ROW_GROUPS
-#define OCEAN_ROW_GROUPS 1          // row groups a workgroup processes back to back (input prefetch depth 1)
-#endif
-#ifndef OCEAN_COL_MINWAVES
-#define OCEAN_COL_MINWAVES 1
-#endif
-
-  template<int N>
-  struct RowCfg
-  {
-    static constexpr int T = Plan<N>::T;
-    static constexpr int K = OCEAN_ROW_FIELDS;
-    static constexpr int ROWS = (OCEAN_ROW_THREADS / T) < 1 ? 1 : (OCEAN_ROW_THREADS / T) > 8 ? 8 : (OCEAN_ROW_THREADS / T);
-    static constexpr int THREADS = ROWS * T;
-    static constexpr int GPW = (N / ROWS) % (16 * OCEAN_ROW_GROUPS) == 0 ? OCEAN_ROW_GROUPS : 1;    // row groups per workgroup, one after the other
-    static constexpr int BLOCKS = N / (ROWS * GPW);                                    // workgroups per cascade
-    static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_ROW_MINWAVES : 1;        // per SIMD
-    static constexpr int PS = 4;                                                       // LDS index padding (see padidx)
-    static constexpr int LINE = LineFFT<N, PS>::LINE;
-    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)ROWS * K * LINE) * sizeof(cf);
-
-    static_assert(K == 1 || K == 3, "OCEAN_ROW_FIELDS must be 1 or 3");
-  };
-
-  // Which band of rows a workgroup takes.  Blocks are dealt round-robin over the 8 XCDs (blockIdx.x % 8, speed
-  // only): each XCD gets a set of bands together with the mirrored bands, because row y reads h0 of row
-  // N-1-y (sim.comp:59) and the dispersion row |y - N/2|, so both come out of that XCD's L2 the second time.
-  template<int N>
-  __device__ __forceinline__ int rowband_of_block(int b)
-  {
-    constexpr int G = RowCfg<N>::BLOCKS;
-
-    if (G % 16 != 0)
-      return b;
-
-    int xcd = b & 7;
-    int slot = b >> 3;
-    int pair = xcd * (G / 16) + (slot >> 1);
-
-    return (slot & 1) ? (G - 1 - pair) : pair;
-  }
-
-  // inputs of ocean.sim for one row segment: this row of h0 and phase, the -k partner row read backwards
-  // (sim.comp:59: index (N-1-y, N-1-x)) and the dispersion (only when an update is pending)
-  template<int N>
-  struct SimInputs
-  {
-    float ph[Plan<N>::E];
-    float om[Plan<N>::E];
-    float2 hk[Plan<N>::E];
-    float2 hm[Plan<N>::E];
-  };
-
-  template<int N>
-  __device__ __forceinline__ void load_sim_inputs(SimInputs<N> &in, float2 const *h0, float const *phase, float const *omega, int y, int t, bool advance)
-  {
-    constexpr int E = Plan<N>::E;
-
-    // a thread's elements are a wave-uniform distance apart: one VGPR offset, SGPR offsets per slot.  The
-    // mirror row runs backwards, so its base is the last slot's element.
-    constexpr int DX = elem_in<N>(0, 1) - elem_in<N>(0, 0);
-
-    __amdgpu_buffer_rsrc_t rph = make_rsrc(phase, (size_t)N * N * sizeof(float));
-    __amdgpu_buffer_rsrc_t rh0 = make_rsrc(h0, (size_t)N * N * sizeof(float2));
-
-    int const x0 = elem_in<N>(t, 0);
-    int const e0 = y * N + x0;
-    int const m0 = (N - 1 - y) * N + (N - 1 - x0 - DX * (E - 1));
-
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-    {
-#ifdef OCEAN_ABLATE_ROWLOAD
-      int x = elem_in<N>(t, s);
-      in.ph[s] = 0.001f * (float)x;
-      in.hk[s] = make_float2(0.01f * (float)(x & 15), 0.02f);
-      in.hm[s] = make_float2(0.03f, 0.01f * (float)(y & 15));
-#else
-      in.ph[s] = buf_load_f32(rph, e0 * 4, DX * s * 4);
-      in.hk[s] = buf_load_f32x2(rh0, e0 * 8, DX * s * 8);
-      in.hm[s] = buf_load_f32x2(rh0, m0 * 8, DX * (E - 1 - s) * 8);
-#endif
-    }
-
-    if (advance)
-    {
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-#ifdef OCEAN_ABLATE_ROWLOAD
-        in.om[s] = 1.0f + 0.001f * (float)s;
-#else
-        in.om[s] = dispersion_lookup(omega, elem_in<N>(t, s), y, N);
-#endif
-    }
-  }
-
-  template<int N>
-  __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MINWAVES) ocean_rowpass_kernel(StepArgs a)
-  {
-    typedef Plan<N> P;
-    typedef LineFFT<N> L;
-    typedef RowCfg<N> C;
-
-    constexpr int E = P::E;
-    constexpr int T = P::T;
-    constexpr int K = C::K;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    int const cascade = blockIdx.y;
-    int const r = threadIdx.x / T;
-    int const t = threadIdx.x % T;
-    int const y0 = rowband_of_block<N>(blockIdx.x) * (C::ROWS * C::GPW) + r;
-
-    cf *midtab = reinterpret_cast<cf*>(smem);
-    cf *line = midtab + L::MIDTAB + r * K * C::LINE;
-
-    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
-      midtab[i] = L::midtab_entry(a.tw, i);
-
-    CascadeConst const cc = a.casc[cascade];
-
-    size_t const plane = (size_t)N * N;
-
-    float2 const *h0 = a.h0 + cascade * plane;
-    float *phase = a.phase + cascade * plane;
-    cf *spec = a.spec + cascade * 3 * plane;
-    cf *halo = a.halo + (size_t)cascade * TileCfg<N>::TILES * 2 * N;
-    float const *omega = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
-
-    // buffer addressing (see buf_*): slot-to-slot distances of a thread's elements, in elements
-    constexpr int DXI = elem_in<N>(0, 1) - elem_in<N>(0, 0);                                            // row-major, inputs
-    constexpr int DBO = (int)(blocked<N>(0, elem_out<N>(0, 1)) - blocked<N>(0, elem_out<N>(0, 0)));     // blocked, outputs
-
-    static_assert(DXI % 8 == 0 && (elem_out<N>(0, 1) - elem_out<N>(0, 0)) % 8 == 0, "slots must be whole 8-column blocks apart");
-
-    __amdgpu_buffer_rsrc_t rphase = make_rsrc(phase, plane * sizeof(float));
-    __amdgpu_buffer_rsrc_t rspec = make_rsrc(spec, 3 * plane * sizeof(cf));
-
-    // this thread's columns t + T s all sit at the same place inside their tile: last column -> left halo of the
-    // next tile, first column -> right halo of the previous one
-    constexpr int W = TileCfg<N>::W;
-    constexpr int NT = TileCfg<N>::TILES;
-    int const halorole = (elem_out<N>(t, 0) % W == W - 1) ? 0 : (elem_out<N>(t, 0) % W == 0) ? 1 : -1;   // same for every slot: slots differ by multiples of 32
-
-    bool const advance = a.ndt > 0;
-
-#if defined(OCEAN_ROW_STAGGER) && OCEAN_ROW_STAGGER > 0
-    // experiment: break the chip-wide load / compute / store lockstep of the first generation of workgroups
-    {
-      // workgroups b, b + 256, b + 512 of the first generation are the ones that share a CU (8 XCDs x 32 CUs)
-      int const lag = ((blockIdx.x + gridDim.x * blockIdx.y) >> 8) % OCEAN_ROW_STAGGER_MOD;
-      for(int i = 0; i < lag * OCEAN_ROW_STAGGER; ++i)
-        __builtin_amdgcn_s_sleep(100);
-    }
-#endif
-
-#ifdef OCEAN_STAMPS
-    unsigned long long *stampbase = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
-#endif
-    OCEAN_STAMP(0);
-
-    typename LineTw<N>::type w;
-    LineTw<N>::load(a.tw, t, w);
-
-    // GPW row groups one after the other.  The inputs of group g + 1 are requested right after group g's
-    // ocean.sim, so their latency is covered by group g's butterflies and barriers; the compiler barriers pin
-    // that order (requests neither sink below the transforms nor pile up at the top of the kernel).
-    SimInputs<N> in;
-
-    load_sim_inputs<N>(in, h0, phase, omega, y0, t, advance);
-
-    order_fence();
-
-#ifdef OCEAN_ROW_UNROLL_GROUPS
-    #pragma unroll
-#else
-    #pragma unroll 1
-#endif
-    for(int g = 0; g < C::GPW; ++g)
-    {
-      int const y = y0 + g * C::ROWS;
-
-      float const ky = wavevector(y, N, cc.scale);
-
-      // update_ocean (ocean.cpp:223-233), each pending dt in turn, then ocean.sim
-      cf h[E];
-      float kinv[E];
-
-      if (advance)
-      {
-        for(int k = 0; k < a.ndt; ++k)
-        {
-          float const dt = a.dt[k];
-
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-            in.ph[s] = advance_phase_fast(in.ph[s], in.om[s] * dt);
-        }
-
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-        {
-#ifdef OCEAN_ABLATE_ROWSTORE
-          if (in.ph[s] == 123456.789f)
-#endif
-          buf_store_f32(in.ph[s], rphase, (y * N + elem_in<N>(t, 0)) * 4, DXI * s * 4);
-        }
-      }
-
-      OCEAN_STAMP(1);
-
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-      {
-        h[s] = sim_height(in.hk[s], in.hm[s], in.ph[s]);
-        kinv[s] = kinv_of(wavevector(elem_in<N>(t, s), N, cc.scale), ky);
-      }
-
-      OCEAN_STAMP(2);
-
-      order_fence();
-
-      if (g + 1 < C::GPW)
-        load_sim_inputs<N>(in, h0, phase, omega, y + C::ROWS, t, advance);
-
-      order_fence();
-
-      // hx = -i h k^x, hy = -i h k^y (sim.comp:68-74) and h itself, each through the row transform
-      if (K == 3)
-      {
-        cf v[K][E];
-
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-        {
-          float kx = wavevector(elem_in<N>(t, s), N, cc.scale) * kinv[s];
-          float kyn = ky * kinv[s];
-
-          v[0][s] = h[s];
-          v[1 % K][s] = cf{ h[s].y * kx, -h[s].x * kx };
-          v[2 % K][s] = cf{ h[s].y * kyn, -h[s].x * kyn };
-        }
-
-        OCEAN_STAMP(3);
-#ifndef OCEAN_ABLATE_ROWFFT
-        fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
-#endif
-        OCEAN_STAMP(4);
-
-        #pragma unroll
-        for(int field = 0; field < K; ++field)
-        {
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-          {
-#ifdef OCEAN_ABLATE_ROWSTORE
-            if (v[field][s].x == 123456.789f)
-#endif
-            buf_store_cf(v[field][s], rspec, (int)blocked<N>(y, elem_out<N>(t, 0)) * 8, (int)((field * plane + (size_t)DBO * s) * 8));
-          }
-        }
-
-        if (OCEAN_HALO_BUFFER && halorole >= 0)
-        {
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-          {
-            int tile = elem_out<N>(t, s) / W;
-            int dst = (halorole == 0) ? (tile + 1) % NT : (tile + NT - 1) % NT;
-
-#ifdef OCEAN_ABLATE_ROWSTORE
-            if (v[0][s].x == 123456.789f)
-#endif
-            halo[((size_t)dst * 2 + halorole) * N + y] = v[0][s];
-          }
-        }
-      }
-      else
-      {
-        #pragma unroll
-        for(int field = 2; field >= 0; --field)
-        {
-          cf v[1][E];
-
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-          {
-            float kc = ((field == 1) ? wavevector(elem_in<N>(t, s), N, cc.scale) : ky) * kinv[s];
-
-            v[0][s] = (field == 0) ? h[s] : cf{ h[s].y * kc, -h[s].x * kc };
-          }
-
-          fft_lines<N, 1, C::PS>(v, t, line, C::LINE, midtab, w, true);
-
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-            buf_store_cf(v[0][s], rspec, (int)blocked<N>(y, elem_out<N>(t, 0)) * 8, (int)((field * plane + (size_t)DBO * s) * 8));
-
-          if (OCEAN_HALO_BUFFER && field == 0 && halorole >= 0)
-          {
-            #pragma unroll
-            for(int s = 0; s < E; ++s)
-            {
-              int tile = elem_out<N>(t, s) / W;
-              int dst = (halorole == 0) ? (tile + 1) % NT : (tile + NT - 1) % NT;
-
-              halo[((size_t)dst * 2 + halorole) * N + y] = v[0][s];
-            }
-          }
-        }
-      }
-
-      OCEAN_STAMP(5);
-
-      order_fence();
-    }
-  }
-
-  //|---------------------- row pass, mirror-paired and persistent ------------
-  // ocean.sim reads h0 at (y, x) and at the mirror index (N-1-y, N-1-x) (sim.comp:59).  Here a workgroup
-  // transforms row y and row N-1-y TOGETHER: the value one row needs from the other is then in a register of
-  // the thread holding the mirrored column, and the thread roles are laid out so that this partner is lane
-  // (L xor (2 HW - 1)) of the same wave -- one ds_bpermute per dword instead of a second trip to L2 per point.
-  // A workgroup walks a contiguous chunk of row pairs; the inputs of the next pair are requested as soon as the
-  // current pair's ocean.sim has consumed its own, so their latency is covered by the three-field transform.
-
-#ifndef OCEAN_ROW_PAIRED
-#define OCEAN_ROW_PAIRED 1
-#endif
-#ifndef OCEAN_PAIR_FIELDS
-#define OCEAN_PAIR_FIELDS 0          // lines per barrier phase: 1, 3, or 0 = by size
-#endif
-
-  template<int N>
-  struct PairCfg
-  {
-    static constexpr int E = Plan<N>::E;
-    static constexpr int T = Plan<N>::T;
-    static constexpr int HW = (T < 32) ? T : 32;                        // lanes of one row in a wave
-    static constexpr int PAIRS = (T >= 128) ? 1 : 128 / T;              // row pairs per workgroup
-    static constexpr int THREADS = 2 * T * PAIRS;
-    static constexpr int K = (OCEAN_PAIR_FIELDS != 0) ? OCEAN_PAIR_FIELDS : (N <= 1024 ? 3 : 1);
-    static constexpr int PS = 4;
-    static constexpr int LINE = LineFFT<N, PS>::LINE;
-    static constexpr int GROUPS = (N / 2) / PAIRS;                      // per cascade
-    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)PAIRS * 2 * K * LINE) * sizeof(cf);
-
-    static_assert(K == 1 || K == 3, "OCEAN_PAIR_FIELDS must be 1 or 3");
-    static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
-    static_assert(!QuadFFT<N>::ENABLED, "the paired row pass uses the generic line transform");
-  };
-
-  // opaque copies: what is derived from them is recomputed where it is used instead of being hoisted out of
-  // the persistent loop into (many) registers
-  __device__ __forceinline__ int launder_v(int x) { asm volatile("" : "+v"(x)); return x; }
-  __device__ __forceinline__ int launder_s(int x) { asm volatile("" : "+s"(x)); return x; }
-
-  template<int N>
-  struct PairInputs
-  {
-    float ph[Plan<N>::E];
-    float om[Plan<N>::E];
-    float2 hk[Plan<N>::E];
-  };
-
-  // group g of the launch -> cascade and first row pair
-  template<int N>
-  __device__ __forceinline__ void pair_request(PairInputs<N> &in, StepArgs const &a, int g, int pr, int half, int t, bool advance)
-  {
-    typedef PairCfg<N> C;
-    constexpr int E = Plan<N>::E;
-    constexpr int DX = elem_in<N>(0, 1) - elem_in<N>(0, 0);
-
-    size_t const plane = (size_t)N * N;
-
-    int const cascade = g / C::GROUPS;
-    int const yp = (g % C::GROUPS) * C::PAIRS + pr;
-    int const y = half ? N - 1 - yp : yp;
-
-    __amdgpu_buffer_rsrc_t rph = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
-    __amdgpu_buffer_rsrc_t rh0 = make_rsrc(a.h0 + cascade * plane, plane * sizeof(float2));
-
-    int const e0 = y * N + elem_in<N>(t, 0);
-
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-    {
-#ifdef OCEAN_ABLATE_ROWLOAD
-      int x = elem_in<N>(t, s);
-      in.ph[s] = 0.001f * (float)x;
-      in.hk[s] = make_float2(0.01f * (float)(x & 15), 0.02f);
-#else
-      in.ph[s] = buf_load_f32(rph, e0 * 4, DX * s * 4);
-      in.hk[s] = buf_load_f32x2(rh0, e0 * 8, DX * s * 8);
-#endif
-    }
-
-    if (advance)
-    {
-      float const *omega = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
-
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-#ifdef OCEAN_ABLATE_ROWLOAD
-        in.om[s] = 1.0f + 0.001f * (float)s;
-#else
-        in.om[s] = dispersion_lookup(omega, elem_in<N>(t, s), y, N);
-#endif
-    }
-  }
-
-  template<int N>
-  __global__ void __launch_bounds__(PairCfg<N>::THREADS) ocean_rowpair_kernel(StepArgs a)
-  {
-    typedef Plan<N> P;
-    typedef LineFFT<N> L;
-    typedef PairCfg<N> C;
-
-    constexpr int E = P::E;
-    constexpr int T = P::T;
-    constexpr int K = C::K;
-    constexpr int HW = C::HW;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    cf *midtab = reinterpret_cast<cf*>(smem);
-
-    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
-      midtab[i] = L::midtab_entry(a.tw, i);
-
-    // thread roles: pair pr of the workgroup; within it waves take HW columns-groups of row y in their lower
-    // lanes and the mirrored column groups of row N-1-y, in the same ascending order, in their upper lanes
-    int const pr0 = threadIdx.x / (2 * T);
-    int const u0 = threadIdx.x % (2 * T);
-    int const half0 = (u0 % (2 * HW)) / HW;
-    int const t0 = half0 ? T - 1 - (HW * (u0 / (2 * HW)) + (2 * HW - 1 - u0 % (2 * HW))) : HW * (u0 / (2 * HW)) + u0 % (2 * HW);
-
-    int const partner = (int)((threadIdx.x & 63) ^ (2 * HW - 1)) << 2;      // ds_bpermute address of the mirror thread
-
-    size_t const plane = (size_t)N * N;
-
-    constexpr int DXI = elem_in<N>(0, 1) - elem_in<N>(0, 0);                                            // row-major, inputs
-    constexpr int DBO = (int)(blocked<N>(0, elem_out<N>(0, 1)) - blocked<N>(0, elem_out<N>(0, 0)));     // blocked, outputs
-
-    static_assert(DXI % 8 == 0 && (elem_out<N>(0, 1) - elem_out<N>(0, 0)) % 8 == 0, "slots must be whole 8-column blocks apart");
-
-    bool const advance = a.ndt > 0;
-
-    typename LineTw<N>::type w;
-    LineTw<N>::load(a.tw, t0, w);
-
-    // this workgroup's chunk of (cascade, row pair group)s
-    int const total = a.cascades * C::GROUPS;
-    int g = (int)(((long long)blockIdx.x * total) / gridDim.x);
-    int const gend = (int)(((long long)(blockIdx.x + 1) * total) / gridDim.x);
-
-    if (g >= gend)
-      return;
-
-#ifdef OCEAN_STAMPS
-    unsigned long long *stampbase = a.stamps + (size_t)blockIdx.x * 32;
-    int const gfirst = g;
-#endif
-    OCEAN_STAMP(0);
-#ifdef OCEAN_STAMPS
-    { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); if (threadIdx.x == 0) stampbase[30] = rt_; }
-#endif
-
-    PairInputs<N> in;
-
-    pair_request<N>(in, a, g, pr0, half0, t0, advance);
-
-    order_fence();
-
-    auto pairstep = [&](int const g) __attribute__((always_inline))
-    {
-      int const t = launder_v(t0);
-      int const half = launder_v(half0);
-      int const pr = launder_v(pr0);
-
-      int const cascade = g / C::GROUPS;
-      int const yp = (g % C::GROUPS) * C::PAIRS + pr;
-      int const y = half ? N - 1 - yp : yp;
-
-      CascadeConst const cc = a.casc[cascade];
-
-      cf *line = midtab + L::MIDTAB + (pr * 2 + half) * K * C::LINE;
-
-      __amdgpu_buffer_rsrc_t rphase = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
-      __amdgpu_buffer_rsrc_t rspec = make_rsrc(a.spec + cascade * 3 * plane, 3 * plane * sizeof(cf));
-
-      float const ky = wavevector(y, N, cc.scale);
-
-#ifdef OCEAN_STAMPS
-      int const sb = 1 + 6 * (g - gfirst);
-#endif
-      OCEAN_STAMP(sb + 0);
-
-      // update_ocean (ocean.cpp:223-233), each pending dt in turn
-      if (advance)
-      {
-        for(int k = 0; k < a.ndt; ++k)
-        {
-          float const dt = a.dt[k];
-
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-            in.ph[s] = advance_phase_fast(in.ph[s], in.om[s] * dt);
-        }
-
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-        {
-#ifdef OCEAN_ABLATE_ROWSTORE
-          if (in.ph[s] == 123456.789f)
-#endif
-          buf_store_f32(in.ph[s], rphase, (y * N + elem_in<N>(t, 0)) * 4, DXI * s * 4);
-        }
-      }
-
-      OCEAN_STAMP(sb + 1);
-
-      // ocean.sim: the mirror value of slot s is slot E-1-s of the partner lane
-      cf h[E];
-      float kinv[E];
-
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-      {
-        float2 hm;
-        hm.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, in.hk[E - 1 - s].x)));
-        hm.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, in.hk[E - 1 - s].y)));
-
-        h[s] = sim_height(in.hk[s], hm, in.ph[s]);
-        kinv[s] = kinv_of(wavevector(elem_in<N>(t, s), N, cc.scale), ky);
-      }
-
-      OCEAN_STAMP(sb + 2);
-
-      order_fence();
-
-      int const gn = g + 1;
-
-      if (gn < gend)
-        pair_request<N>(in, a, gn, pr, half, t, advance);
-
-      order_fence();
-
-      // h, hx = -i h k^x, hy = -i h k^y (sim.comp:68-74), each through the row transform
-      if constexpr (K == 3)
-      {
-        cf v[K][E];
-
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-        {
-          float kx = wavevector(elem_in<N>(t, s), N, cc.scale) * kinv[s];
-          float kyn = ky * kinv[s];
-
-          v[0][s] = h[s];
-          v[1 % K][s] = cf{ h[s].y * kx, -h[s].x * kx };
-          v[2 % K][s] = cf{ h[s].y * kyn, -h[s].x * kyn };
-        }
-
-        OCEAN_STAMP(sb + 3);
-#ifndef OCEAN_ABLATE_ROWFFT
-        fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
-#endif
-        OCEAN_STAMP(sb + 4);
-
-        #pragma unroll
-        for(int field = 0; field < K; ++field)
-        {
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-          {
-#ifdef OCEAN_ABLATE_ROWSTORE
-            if (v[field][s].x == 123456.789f)
-#endif
-            buf_store_cf(v[field][s], rspec, (int)blocked<N>(y, elem_out<N>(t, 0)) * 8, (int)((field * plane + (size_t)DBO * s) * 8));
-          }
-        }
-      }
-      else
-      {
-        #pragma unroll
-        for(int field = 2; field >= 0; --field)
-        {
-          cf v[1][E];
-
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-          {
-            float kc = ((field == 1) ? wavevector(elem_in<N>(t, s), N, cc.scale) : ky) * kinv[s];
-
-            v[0][s] = (field == 0) ? h[s] : cf{ h[s].y * kc, -h[s].x * kc };
-          }
-
-          fft_lines<N, 1, C::PS>(v, t, line, C::LINE, midtab, w, true);
-
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-            buf_store_cf(v[0][s], rspec, (int)blocked<N>(y, elem_out<N>(t, 0)) * 8, (int)((field * plane + (size_t)DBO * s) * 8));
-        }
-      }
-
-      OCEAN_STAMP(sb + 5);
-
-      order_fence();
-    };
-
-    // The first pair is peeled off the loop: the loop is then entered with the same queue of outstanding
-    // requests as its back edge carries (next inputs, then this pair's stores), so the compiler's wait for the
-    // inputs counts the younger stores instead of draining them (a rolled loop drained every store per pair).
-    pairstep(g);
-
-    #pragma unroll 1
-    for(++g; g < gend; ++g)
-      pairstep(g);
-
-#ifdef OCEAN_STAMPS
-    { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_) :: "memory"); if (threadIdx.x == 0) stampbase[31] = rt_; }
-    OCEAN_STAMP(29);
-#endif
-  }
-
-  //|---------------------- column pass + map ---------------------------------
-
-  template<int N>
-  struct ColCfg
-  {
-    static constexpr int T = Plan<N>::T;
-    static constexpr int CPT = TileCfg<N>::CPT;
-    static constexpr int WC = TileCfg<N>::WC;                           // threads across a tile row
-    static constexpr int W = TileCfg<N>::W;                             // tile width in columns
-    static constexpr int THREADS = WC * T;
-    static constexpr int MINWAVES = (THREADS >= 512) ? OCEAN_COL_MINWAVES : 1;
-#ifndef OCEAN_COL_PAD_SHIFT
-#define OCEAN_COL_PAD_SHIFT 3
-#endif
-#ifndef OCEAN_COL_CS_EXTRA
-#define OCEAN_COL_CS_EXTRA 12
-#endif
-    static constexpr int PS = OCEAN_COL_PAD_SHIFT;                      // LDS index padding (see padidx)
-    static constexpr int CS = LineFFT<N, PS>::LINE + OCEAN_COL_CS_EXTRA;   // LDS line stride (complex); measured best of a small sweep
-    static constexpr int SY = N + 4;                                    // height exchange: column stride (floats)
-    static constexpr int HR = (2 + WC - 1) / WC;                        // halo rounds (1 unless WC == 1)
-
-#ifndef OCEAN_COL_FUSE_HALO
-#define OCEAN_COL_FUSE_HALO 0      // measured: no gain at 1024^2 x 4 (54.9 us fused vs 53.2 us), kept as an option
-#endif
-    // one column per thread: the two halo columns are transformed together with field 0 (their own two LDS
-    // lines, the same barriers) instead of in a round of their own, which at W = 4 was a quarter of the work
-    static constexpr bool FUSE = (OCEAN_COL_FUSE_HALO != 0) && CPT == 1 && WC >= 2 && !QuadFFT<N>::ENABLED;
-
-    // LDS carve, in bytes: first middle-pass twiddles | heights of the two halo columns | W transform lines
-    // (every column of the tile is in flight), later reused for the heights of the tile's own columns
-    static constexpr size_t OFF_HALO = (size_t)LineFFT<N>::MIDTAB * sizeof(cf);
-    static constexpr size_t OFF_MAIN = OFF_HALO + (size_t)2 * SY * sizeof(float);
-    static constexpr size_t MAIN_FFT = (size_t)(FUSE ? W + 2 : (W > 2 ? W : 2)) * CS * sizeof(cf);
-    static constexpr size_t MAIN_DZ = (size_t)W * SY * sizeof(float);
-    static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
-
-    static_assert(CPT == 1 || CPT == 2, "OCEAN_COL_CPT must be 1 or 2");
-    static_assert(N % W == 0, "bad tile width");
-    static_assert(OFF_MAIN % 16 == 0, "LDS carve must stay 16-byte aligned");
-  };
-
-  // CPT adjacent spectrum values of one row: one 8- or 16-byte load
-  template<int CPT> struct SpecLoad;
-
-  template<> struct SpecLoad<1>
-  {
-    cf v;
-    __device__ __forceinline__ void load(cf const *p) { v = *p; }
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voffset, int soffset) { v = buf_load_cf(r, voffset, soffset); }
-    __device__ __forceinline__ cf get(int) const { return v; }
-  };
-
-  template<> struct SpecLoad<2>
-  {
-    float4 v;
-    __device__ __forceinline__ void load(cf const *p) { v = *reinterpret_cast<float4 const*>(p); }
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voffset, int soffset) { v = buf_load_f32x4(r, voffset, soffset); }
-    __device__ __forceinline__ cf get(int i) const { return i == 0 ? cf{ v.x, v.y } : cf{ v.z, v.w }; }
-  };
-
-  template<int N>
-  __global__ void __launch_bounds__(ColCfg<N>::THREADS, ColCfg<N>::MINWAVES) ocean_colpass_kernel(StepArgs a)
-  {
-    typedef Plan<N> P;
-    typedef LineFFT<N> L;
-    typedef ColCfg<N> C;
-
-    constexpr int E = P::E;
-    constexpr int T = P::T;
-    constexpr int W = C::W;
-    constexpr int WC = C::WC;
-    constexpr int CPT = C::CPT;
-    constexpr int HR = C::HR;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    cf *midtab = reinterpret_cast<cf*>(smem);
-    float *dzhalo = reinterpret_cast<float*>(smem + C::OFF_HALO);     // [2][SY]: columns x0 - 1 and x0 + W
-    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [W][CS]
-    float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [W][SY], after the transforms
-
-    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
-      midtab[i] = L::midtab_entry(a.tw, i);
-
-    // blocks are dealt round-robin over the 8 XCDs (speed only): give each XCD a contiguous band of tiles so that
-    // neighbouring tiles, which share their border columns' cache lines, meet in the same L2
-    constexpr int NT = TileCfg<N>::TILES;
-    int const tile = (NT % 8 == 0) ? (int)(blockIdx.x & 7) * (NT / 8) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-
-    int const cascade = blockIdx.y;
-    int const x0 = tile * W;
-
-    CascadeConst const cc = a.casc[cascade];
-
-    size_t const plane = (size_t)N * N;
-
-    cf const *spec = a.spec + cascade * 3 * plane;
-    cf const *halocols = a.halo + ((size_t)cascade * NT + tile) * 2 * N;
-    (void)halocols;
-    float4 *layer0 = a.maps + (size_t)cascade * 2 * plane;
-
-    // buffer addressing (see buf_*): slot-to-slot distances of a thread's rows
-    constexpr int DBI = (int)(blocked<N>(elem_in<N>(0, 1), 0) - blocked<N>(elem_in<N>(0, 0), 0));      // blocked spectrum, inputs (elements)
-    constexpr int DYO = elem_out<N>(0, 1) - elem_out<N>(0, 0);                                         // map rows, outputs
-
-    static_assert((elem_in<N>(0, 1) - elem_in<N>(0, 0)) % 8 == 0, "slots must be whole 8-row blocks apart");
-
-    __amdgpu_buffer_rsrc_t rspec = make_rsrc(spec, 3 * plane * sizeof(cf));
-    __amdgpu_buffer_rsrc_t rmaps = make_rsrc(layer0, 2 * plane * sizeof(float4));
-
-#if defined(OCEAN_COL_STAGGER) && OCEAN_COL_STAGGER > 0
-    {
-      // one workgroup per CU: delay every other CU of an XCD so that half the chip transforms while the other
-      // half is in its load or store phase
-      int const lag = ((blockIdx.x + gridDim.x * blockIdx.y) >> 3) % OCEAN_COL_STAGGER_MOD;
-      for(int i = 0; i < lag * OCEAN_COL_STAGGER; ++i)
-        __builtin_amdgcn_s_sleep(100);
-    }
-#endif
-
-#ifdef OCEAN_STAMPS
-    unsigned long long *stampbase = a.stamps + ((size_t)(gridDim.y + blockIdx.y) * 8192 + blockIdx.x) * 16;
-#endif
-    OCEAN_STAMP(0);
-
-    // thread roles.  halo rounds: line slot hc = thread / T, row group ht = thread % T.
-    // main rounds: column group cp (fastest over lanes) = columns xa .. xa + CPT - 1; row group t.
-    int const hc = threadIdx.x / T;
-    int const ht = threadIdx.x % T;
-
-    // (with quad butterflies the four lanes of a quad must be the four threads 4j .. 4j+3 of one line)
-    int const cp = QuadFFT<N>::ENABLED ? (int)(threadIdx.x >> 2) % WC : (int)threadIdx.x % WC;
-    int const t = QuadFFT<N>::ENABLED ? (int)((threadIdx.x / (4 * WC)) << 2 | (threadIdx.x & 3)) : (int)threadIdx.x / WC;
-    int const xa = x0 + CPT * cp;
-
-    // all requests for the first two rounds go out before any transform: the halo columns (height only) and
-    // field 0; later every field is requested one round ahead of its use
-    cf vh[HR][E];
-
-    #pragma unroll
-    for(int hr = 0; hr < HR; ++hr)
-    {
-      int const side = hr * WC + hc;
-
-      if (side < 2)
-      {
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-        {
-#ifdef OCEAN_ABLATE_COLLOAD
-          vh[hr][s] = cf{ 0.01f * (float)(ht & 31), 0.02f * (float)s };
-#elif OCEAN_HALO_BUFFER
-          vh[hr][s] = halocols[side * N + elem_in<N>(ht, s)];
-#else
-          vh[hr][s] = buf_load_cf(rspec, (int)blocked<N>(elem_in<N>(ht, 0), (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1))) * 8, DBI * s * 8);
-#endif
-        }
-      }
-    }
-
-    SpecLoad<CPT> q[2][E];
-
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-    {
-#ifdef OCEAN_ABLATE_COLLOAD
-      q[0][s].load(midtab + ((t + s + cp) & 31));
-#else
-      q[0][s].load(rspec, (int)blocked<N>(elem_in<N>(t, 0), xa) * 8, DBI * s * 8);
-#endif
-    }
-
-    // halo rounds: height of the two columns bordering the tile (periodic, map.comp:58)
-    typename LineTw<N>::type hw;
-    LineTw<N>::load(a.tw, ht, hw);
-
-    if constexpr (!C::FUSE)
-    {
-      #pragma unroll
-      for(int hr = 0; hr < HR; ++hr)
-      {
-        int const side = hr * WC + hc;
-        bool const halo = side < 2;
-        int const hx = (side == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
-        float const hsigma = ((hx + elem_out<N>(ht, 0)) & 1) ? -1.0f : 1.0f;
-
-        cf v[1][E];
-
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-          v[0][s] = vh[hr][s];
-
-        OCEAN_STAMP(1);
-
-        fft_lines<N, 1, C::PS>(v, ht, lines + hc * C::CS, C::CS, midtab, hw, halo);
-
-        OCEAN_STAMP(2);
-
-        if (halo)
-        {
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-            dzhalo[side * C::SY + elem_out<N>(ht, s)] = v[0][s].x * hsigma;
-        }
-      }
-    }
-
-    typename LineTw<N>::type w;
-    LineTw<N>::load(a.tw, t, w);
-
-    // (-1)^(x+y) of map.comp:60; a thread's rows differ by even amounts: fixed per thread and column, alternating over columns
-    float sig[CPT];
-
-    #pragma unroll
-    for(int c = 0; c < CPT; ++c)
-      sig[c] = ((xa + c + elem_out<N>(t, 0)) & 1) ? -1.0f : 1.0f;
-
-    float dx[CPT][E], dy[CPT][E], dz[CPT][E];
-
-    // height, then choppy x / y displacement: Re(column transform) * sigma [* choppiness] (map.comp:62-64)
-    #pragma unroll
-    for(int field = 0; field < 3; ++field)
-    {
-      if (field + 1 < 3)
-      {
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-        {
-#ifdef OCEAN_ABLATE_COLLOAD
-          q[(field + 1) & 1][s].load(midtab + ((t + s + cp + field) & 31));
-#else
-          q[(field + 1) & 1][s].load(rspec, (int)blocked<N>(elem_in<N>(t, 0), xa) * 8, (int)(((field + 1) * plane + (size_t)DBI * s) * 8));
-#endif
-        }
-      }
-
-      cf v[CPT][E];
-
-      #pragma unroll
-      for(int c = 0; c < CPT; ++c)
-      {
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-          v[c][s] = q[field & 1][s].get(c);
-      }
-
-      OCEAN_STAMP(3 + 2 * field);
-#ifndef OCEAN_ABLATE_COLFFT
-      if constexpr (C::FUSE)
-      {
-        if (field == 0)
-        {
-          // the halo columns ride along: threads hc < 2 carry a second line (slots W, W + 1)
-          bool const halo = hc < 2;
-          int const hx = (hc == 0) ? ((x0 + N - 1) & (N - 1)) : ((x0 + W) & (N - 1));
-          float const hsigma = ((hx + elem_out<N>(ht, 0)) & 1) ? -1.0f : 1.0f;
-
-          fft_pair<N, C::PS>(v[0], t, lines + cp * C::CS, w, true, vh[0], ht, lines + (W + hc) * C::CS, hw, halo, midtab);
-
-          if (halo)
-          {
-            #pragma unroll
-            for(int s = 0; s < E; ++s)
-              dzhalo[hc * C::SY + elem_out<N>(ht, s)] = vh[0][s].x * hsigma;
-          }
-        }
-        else
-          fft_lines<N, CPT, C::PS>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
-      }
-      else
-        fft_lines<N, CPT, C::PS>(v, t, lines + CPT * cp * C::CS, C::CS, midtab, w, true);
-#endif
-      OCEAN_STAMP(4 + 2 * field);
-
-      #pragma unroll
-      for(int c = 0; c < CPT; ++c)
-      {
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-        {
-          if (field == 0) dz[c][s] = v[c][s].x * sig[c];
-          if (field == 1) dx[c][s] = v[c][s].x * sig[c] * cc.choppiness;
-          if (field == 2) dy[c][s] = v[c][s].x * sig[c] * cc.choppiness;
-        }
-      }
-    }
-
-    // exchange heights (the transform lines are free after the last barrier of fft_lines)
-    float *own = dzmain + (CPT * cp) * C::SY;
-
-    #pragma unroll
-    for(int c = 0; c < CPT; ++c)
-    {
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-        own[c * C::SY + elem_out<N>(t, s)] = dz[c][s];
-    }
-
-    __syncthreads();
-
-    OCEAN_STAMP(9);
-
-    float const *left = (cp == 0) ? dzhalo : own - C::SY;
-    float const *right = (cp == WC - 1) ? dzhalo + C::SY : own + CPT * C::SY;
-
-    // central-difference normal (map.comp:72-77) and the two image stores (map.comp:79-80)
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-    {
-      int y = elem_out<N>(t, s);
-      int yu = (y + N - 1) & (N - 1);
-      int yd = (y + 1) & (N - 1);
-
-      float nz = cc.nz;
-
-      int const o0 = (elem_out<N>(t, 0) * N + xa) * 16;                 // byte offset of this thread's first texel, slot 0
-
-      #pragma unroll
-      for(int c = 0; c < CPT; ++c)
-      {
-        float l = (c == 0) ? left[y] : dz[c > 0 ? c - 1 : 0][s];
-        float r = (c == CPT - 1) ? right[y] : dz[c + 1 < CPT ? c + 1 : 0][s];
-
-        float nx = l - r;
-        float ny = own[c * C::SY + yd] - own[c * C::SY + yu];
-        float inv = rsqrtf(nx * nx + ny * ny + nz * nz);
-
-#ifdef OCEAN_ABLATE_COLSTORE
-        if (nx * inv + dx[c][s] + dy[c][s] == 123456.789f)
-#endif
-        {
-          buf_store_f32x4(make_float4(dx[c][s], dy[c][s], dz[c][s], 0.0f), rmaps, o0, (DYO * s * N + c) * 16);
-          buf_store_f32x4(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, (int)(((size_t)DYO * s * N + c + plane) * 16));
-        }
-      }
-    }
-
-    OCEAN_STAMP(10);
   }
 
   //|---------------------- packed step: two complex transforms instead of three --
@@ -1524,6 +415,8 @@ namespace ocean
   //
   //     C = h_H + i hx_H                        -> Re = height,          Im = choppy x
   //     D = hy_H + i (-2 i sin(2 pi n / N)) h_H -> Re = choppy y,        Im = height[x-1] - height[x+1]
+  //
+  // (stored as 2 C and 2 D: F[k] + conj(F[-k]) without the halving, which the column pass folds into its sign factor)
   //
   // (the second term of D is the transfer function of the central difference of map.comp:72-75, periodic wrap
   // included: the x slope needs no neighbouring columns any more).  So the row pass transforms and writes two
@@ -1537,14 +430,8 @@ namespace ocean
   // is -pi N scale at both): the general form  F_H = (F[k] + conj(F[-k])) / 2  is evaluated with the sign that
   // applies, so the result equals the reference's three transforms to rounding (tests/test_oracle_pins.py).
 
-#ifndef OCEAN_PACKED
-#define OCEAN_PACKED 1
-#endif
-
-  typedef float4 cd;    // (C.re, C.im, D.re, D.im) of one grid point
-
   template<int N>
-  struct PackRowCfg
+  struct RowCfg
   {
     static constexpr int E = Plan<N>::E;
     static constexpr int T = Plan<N>::T;
@@ -1557,7 +444,6 @@ namespace ocean
     static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)PAIRS * 2 * K * LINE) * sizeof(cf);
 
     static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
-    static_assert(!QuadFFT<N>::ENABLED, "the packed row pass uses the generic line transform");
   };
 
   // sin(alpha + 2 pi s / E) for the E slots of a thread from (cos, sin)(alpha)
@@ -1593,11 +479,11 @@ namespace ocean
   }
 
   template<int N>
-  __global__ void __launch_bounds__(PackRowCfg<N>::THREADS) ocean_rowpack_kernel(StepArgs a)
+  __global__ void __launch_bounds__(RowCfg<N>::THREADS) ocean_rowpass_kernel(StepArgs a)
   {
     typedef Plan<N> P;
     typedef LineFFT<N> L;
-    typedef PackRowCfg<N> C;
+    typedef RowCfg<N> C;
 
     constexpr int E = P::E;
     constexpr int T = P::T;
@@ -1644,9 +530,15 @@ namespace ocean
 
     __amdgpu_buffer_rsrc_t rphase = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
     __amdgpu_buffer_rsrc_t rh0 = make_rsrc(h0, plane * sizeof(float2));
-    __amdgpu_buffer_rsrc_t rspec = make_rsrc(reinterpret_cast<cd*>(a.spec) + cascade * plane, plane * sizeof(cd));
+    __amdgpu_buffer_rsrc_t rspec = make_rsrc(a.spec + cascade * plane, plane * sizeof(cd));
 
     bool const advance = a.ndt > 0;
+
+#ifdef OCEAN_STAMPS
+    unsigned long long *stampbase = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+#endif
+    OCEAN_STAMP_WHERE();
+    OCEAN_STAMP(0);
 
     // inputs of ocean.sim: this row of phase and h0, the mirror row (sim.comp:59) backwards
     float ph[E], om[E];
@@ -1687,6 +579,9 @@ namespace ocean
     typename LineTw<N>::type w;
     LineTw<N>::load(a.tw, t, w);
 
+    OCEAN_WAIT_LOADS();
+    OCEAN_STAMP(1);
+
     // update_ocean (ocean.cpp:223-233), each pending dt in turn
     if (advance)
     {
@@ -1715,15 +610,20 @@ namespace ocean
     #pragma unroll
     for(int s = 0; s < E; ++s)
     {
-      h[s] = sim_height(hk[s], hm[s], ph[s]);
+      h[s] = sim_height_products(hk[s], hm[s], ph[s]);
 
       swap_out[padidx<C::PS>(t + T * s)] = h[s];
     }
 
     __syncthreads();
 
+    OCEAN_STAMP(2);
+
     float const ky = wavevector(y, N, cc.scale);
-    float const sy = (y == 0) ? -1.0f : 1.0f;
+
+    // k^ keeps its sign where the index is its own negative (x = 0, y = 0): there the partner enters hx / hy negated
+    float const cy = (y == 0) ? -2.0f : 0.0f;
+    float const cx = (t == 0) ? -2.0f : 0.0f;
 
     cf v[K][E];
 
@@ -1737,29 +637,31 @@ namespace ocean
       cf const b = cf{ n.x, -n.y };                                   // conj(h~[-k])
 
       float const kx = wavevector(x, N, cc.scale);
-      float const kinv = kinv_of(kx, ky);
+      float const kinv = kinv_fast(kx, ky);
       float const khx = kx * kinv, khy = ky * kinv;
 
-      // Hermitian parts of h~, and of h~ as it enters hx and hy (k^ does not change sign where the index is its own negative)
-      float const sx = (s == 0 && t == 0) ? -1.0f : 1.0f;
-
-      cf const hh = cf{ 0.5f * (h[s].x + b.x), 0.5f * (h[s].y + b.y) };
-      cf const hhx = (s == 0) ? cf{ 0.5f * (h[s].x + sx * b.x), 0.5f * (h[s].y + sx * b.y) } : hh;
-      cf const hhy = cf{ 0.5f * (h[s].x + sy * b.x), 0.5f * (h[s].y + sy * b.y) };
+      // TWICE the Hermitian parts (the column pass folds the 1/2 into its sign factor): of h~, and of h~ as it enters hx, hy
+      cf const hh = cf{ h[s].x + b.x, h[s].y + b.y };
+      cf const hhx = (s == 0) ? cf{ fmaf(cx, b.x, hh.x), fmaf(cx, b.y, hh.y) } : hh;
+      cf const hhy = cf{ fmaf(cy, b.x, hh.x), fmaf(cy, b.y, hh.y) };
 
       float const s2 = 2.0f * slot_sine<E>(ca, s);                    // 2 sin(2 pi x / N)
 
       // C = h_H + i (-i k^x hhx) = h_H + k^x hhx ;  D = -i k^y hhy + 2 sin(theta) h_H
-      v[0][s] = cf{ hh.x + khx * hhx.x, hh.y + khx * hhx.y };
-      v[1][s] = cf{ khy * hhy.y + s2 * hh.x, s2 * hh.y - khy * hhy.x };
+      v[0][s] = cf{ fmaf(khx, hhx.x, hh.x), fmaf(khx, hhx.y, hh.y) };
+      v[1][s] = cf{ fmaf(khy, hhy.y, s2 * hh.x), fmaf(-khy, hhy.x, s2 * hh.y) };
     }
 
     // every thread has fetched its partner values before pass 0 overwrites the lines
     __syncthreads();
 
+    OCEAN_STAMP(3);
+
 #ifndef OCEAN_ABLATE_ROWFFT
     fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
 #endif
+
+    OCEAN_STAMP(4);
 
     #pragma unroll
     for(int s = 0; s < E; ++s)
@@ -1769,17 +671,25 @@ namespace ocean
 #endif
       buf_store_f32x4(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
     }
+
+    OCEAN_STAMP(5);
   }
 
   template<int N>
-  struct PackColCfg
+  struct ColCfg
   {
     static constexpr int E = Plan<N>::E;
     static constexpr int T = Plan<N>::T;
-    static constexpr int WRAW = ((T <= 128) ? 512 : 1024) / T;
-    static constexpr int W = WRAW > 8 ? 8 : WRAW;                       // columns per workgroup, one per thread group
+#ifndef OCEAN_COL_THREADS
+#define OCEAN_COL_THREADS 0        // 0 = by size
+#endif
+#ifndef OCEAN_COL_FIELDS
+#define OCEAN_COL_FIELDS 2         // fields per barrier phase: 2 (together) or 1 (one after the other, half the LDS)
+#endif
+    static constexpr int WRAW = ((OCEAN_COL_THREADS != 0) ? OCEAN_COL_THREADS : ((T <= 128) ? 512 : 1024)) / T;
+    static constexpr int W = WRAW > 8 ? 8 : (WRAW < 1 ? 1 : WRAW);      // columns per workgroup, one per thread group
     static constexpr int THREADS = W * T;
-    static constexpr int K = 2;
+    static constexpr int K = OCEAN_COL_FIELDS;
 #ifndef OCEAN_COL_PAD_SHIFT
 #define OCEAN_COL_PAD_SHIFT 3
 #endif
@@ -1800,12 +710,15 @@ namespace ocean
     static_assert(OFF_MAIN % 16 == 0, "LDS carve must stay 16-byte aligned");
   };
 
+  // One tile per workgroup.  (A persistent variant -- workgroups walking a run of tiles, the next tile's values
+  // requested ahead and the map stores draining behind -- was measured 15 % slower: this pass runs at the rate the
+  // memory system moves its 48 B/pt, and queueing more requests per workgroup only delays the first ones.)
   template<int N>
-  __global__ void __launch_bounds__(PackColCfg<N>::THREADS) ocean_colpack_kernel(StepArgs a)
+  __global__ void __launch_bounds__(ColCfg<N>::THREADS) ocean_colpass_kernel(StepArgs a)
   {
     typedef Plan<N> P;
     typedef LineFFT<N> L;
-    typedef PackColCfg<N> C;
+    typedef ColCfg<N> C;
 
     constexpr int E = P::E;
     constexpr int T = P::T;
@@ -1815,7 +728,7 @@ namespace ocean
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     cf *midtab = reinterpret_cast<cf*>(smem);
-    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [W][K][CS]
+    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [K][W][CS]
     float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [W][SY], after the transforms
 
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
@@ -1839,8 +752,14 @@ namespace ocean
 
     static_assert(T % 8 == 0, "slots must be whole 8-row blocks apart");
 
-    __amdgpu_buffer_rsrc_t rspec = make_rsrc(reinterpret_cast<cd const*>(a.spec) + cascade * plane, plane * sizeof(cd));
+    __amdgpu_buffer_rsrc_t rspec = make_rsrc(a.spec + cascade * plane, plane * sizeof(cd));
     __amdgpu_buffer_rsrc_t rmaps = make_rsrc(a.maps + (size_t)cascade * 2 * plane, 2 * plane * sizeof(float4));
+
+#ifdef OCEAN_STAMPS
+    unsigned long long *stampbase = a.stamps + ((size_t)65536 + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+#endif
+    OCEAN_STAMP_WHERE();
+    OCEAN_STAMP(0);
 
     float4 q[E];
 
@@ -1857,7 +776,10 @@ namespace ocean
     typename LineTw<N>::type w;
     LineTw<N>::load(a.tw, t, w);
 
-    cf v[K][E];
+    OCEAN_WAIT_LOADS();
+    OCEAN_STAMP(1);
+
+    cf v[2][E];
 
     #pragma unroll
     for(int s = 0; s < E; ++s)
@@ -1867,11 +789,33 @@ namespace ocean
     }
 
 #ifndef OCEAN_ABLATE_COLFFT
-    fft_lines<N, K, C::PS>(v, t, lines + (K * cp) * C::CS, C::CS, midtab, w, true);
+    if constexpr (K == 2)
+      fft_lines<N, 2, C::PS>(v, t, lines + cp * C::CS, W * C::CS, midtab, w, true);    // lines [K][W][CS]: columns CS apart as tuned for bank spread
+    else
+    {
+      #pragma unroll
+      for(int f = 0; f < 2; ++f)
+      {
+        cf u[1][E];
+
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+          u[0][s] = v[f][s];
+
+        fft_lines<N, 1, C::PS>(u, t, lines + cp * C::CS, C::CS, midtab, w, true);
+
+        #pragma unroll
+        for(int s = 0; s < E; ++s)
+          v[f][s] = u[0][s];
+      }
+    }
 #endif
 
+    OCEAN_STAMP(2);
+
     // (-1)^(x+y) of map.comp:60; a thread's rows differ by even amounts
-    float const sig = ((x + t) & 1) ? -1.0f : 1.0f;
+    // times the 1/2 of the Hermitian parts, which the row pass leaves out
+    float const sig = ((x + t) & 1) ? -0.5f : 0.5f;
     float const sigchop = sig * cc.choppiness;
 
     // the transform lines are free after the last barrier of fft_lines: heights of this column for the y slope
@@ -1882,6 +826,8 @@ namespace ocean
       own[t + T * s] = v[0][s].x * sig;
 
     __syncthreads();
+
+    OCEAN_STAMP(3);
 
     float const nz = cc.nz;
 
@@ -1909,6 +855,8 @@ namespace ocean
         buf_store_f32x4(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, (int)(((size_t)T * s * N + plane) * 16));
       }
     }
+
+    OCEAN_STAMP(4);
   }
 
   // blocked packed spectrum -> two row-major complex planes (datum_ocean_debug_rowpass)
@@ -2015,19 +963,6 @@ namespace ocean
       h[i] = hh;
       hx[i] = cf{ hh.y * kn.x, -hh.x * kn.x };
       hy[i] = cf{ hh.y * kn.y, -hh.x * kn.y };
-    }
-  }
-
-  // blocked work spectrum -> row-major (datum_ocean_debug_rowpass)
-  __global__ void ocean_unblock_kernel(cf const *spec, int N, cf *out)
-  {
-    size_t const plane = (size_t)N * N;
-
-    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x)
-    {
-      int y = (int)(i / N), x = (int)(i % N);
-
-      out[i] = spec[((size_t)((y >> 3) * (N / 8) + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7)];
     }
   }
 

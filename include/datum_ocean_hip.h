@@ -153,9 +153,10 @@ int datum_ocean_debug_sim(datum_ocean_t ctx, int cascade, float *h, float *hx, f
 
 /* the work spectrum after the row pass of the last datum_ocean_displace, converted back to row-major: N*N*2 floats
  * each, host pointers.  The module transforms two packed fields instead of the reference's three (what
- * ocean.map keeps is the real part of each transform): with F_H[y][x] = (F[y][x] + conj(F[(N-y)%N][(N-x)%N])) / 2,
- *   c = rows of ocean.fftx applied to  C = h_H + i hx_H
- *   d = rows of ocean.fftx applied to  D = hy_H + 2 sin(2 pi x / N) h_H
+ * ocean.map keeps is the real part of each transform): with F_S[y][x] = F[y][x] + conj(F[(N-y)%N][(N-x)%N])
+ * (twice the Hermitian part; the halving is folded into the column pass),
+ *   c = rows of ocean.fftx applied to  C = h_S + i hx_S
+ *   d = rows of ocean.fftx applied to  D = hy_S + 2 sin(2 pi x / N) h_S
  * where h, hx, hy are ocean.sim's outputs (datum_ocean_debug_sim). */
 int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *c, float *d);
 

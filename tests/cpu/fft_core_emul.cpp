@@ -83,82 +83,3 @@ extern "C" int emul_line_ifft(int N, float const *in, float *out)
   }
   return 0;
 }
-
-// ---- N = 1024 quad (radix-32 x radix-32) path: the four lanes of a quad are emulated together; the cross-lane
-// radix-4 uses the same per-lane formula (quad_pair, the lane-3 rotation, the signs) as the DPP code on the device
-static void emul_quad_radix4(cf (&u)[4][8])
-{
-  for(int q = 0; q < 8; ++q)
-  {
-    cf y[4], e[4], z[4];
-    for(int a = 0; a < 4; ++a) y[a] = u[a][q];
-    for(int a = 0; a < 4; ++a)
-    {
-      float s1 = (a & 2) ? -1.0f : 1.0f;
-      e[a] = quad_pair(y[a], y[a ^ 2], s1);
-      if (a == 3) e[a] = cf{ -e[a].y, e[a].x };
-    }
-    for(int a = 0; a < 4; ++a)
-    {
-      float s2 = (a & 1) ? -1.0f : 1.0f;
-      z[a] = quad_pair(e[a], e[a ^ 1], s2);
-    }
-    for(int a = 0; a < 4; ++a) u[a][q] = z[a];
-  }
-}
-
-extern "C" int emul_line_ifft_quad1024(float const *in, float *out)
-{
-  const int N = 1024, T = 128;
-
-  std::vector<cf> tw(N);
-  for(int k = 0; k < N; ++k)
-  {
-    double a = 2.0 * M_PI * k / N;
-    tw[k] = cf{ (float)std::cos(a), (float)std::sin(a) };
-  }
-
-  std::vector<cf> lds(N);
-  cf u[T][8];
-  QuadTwiddles w[T];
-
-  // check the swizzle is a bijection
-  std::vector<int> seen(N, 0);
-  for(int i = 0; i < N; ++i) { int p = quad_swizzle(i); if (p < 0 || p >= N || seen[p]++) return -2; }
-
-  for(int t = 0; t < T; ++t)
-  {
-    quad_load_twiddles(tw.data(), t, w[t]);
-    for(int s = 0; s < 8; ++s)
-    {
-      int x = quad_elem_in(t, s);
-      u[t][s] = cf{ in[2*x], in[2*x+1] };
-    }
-  }
-
-  // pass 0
-  for(int t = 0; t < T; ++t) quad_radix32_local(u[t], w[t]);
-  for(int j = 0; j < T / 4; ++j) emul_quad_radix4(*reinterpret_cast<cf (*)[4][8]>(&u[4*j]));
-  for(int t = 0; t < T; ++t)
-    for(int q = 0; q < 8; ++q)
-      lds[quad_swizzle(32 * (t >> 2) + q + 8 * bitrev2(t & 3))] = u[t][q];
-
-  // pass 1
-  for(int t = 0; t < T; ++t)
-  {
-    for(int b = 0; b < 8; ++b)
-      u[t][b] = cmul(lds[quad_swizzle((t >> 2) + 32 * (t & 3) + 128 * b)], w[t].pass1[b]);
-    quad_radix32_local(u[t], w[t]);
-  }
-  for(int j = 0; j < T / 4; ++j) emul_quad_radix4(*reinterpret_cast<cf (*)[4][8]>(&u[4*j]));
-
-  for(int t = 0; t < T; ++t)
-    for(int s = 0; s < 8; ++s)
-    {
-      int x = quad_elem_out(t, s);
-      out[2*x] = u[t][s].x;
-      out[2*x+1] = u[t][s].y;
-    }
-
-  return 0;
-}

@@ -45,19 +45,3 @@ def test_line_transform_impulses(emul):
         n = np.arange(N)
         want = np.exp(2j * np.pi * ((k * n) % N) / N)
         assert np.abs((out[:, 0] + 1j * out[:, 1]) - want).max() < 2e-6, k
-
-
-def test_quad_radix32_path(emul):
-    # N = 1024 as 32 x 32 with quad (cross-lane) butterflies and the XOR-swizzled single exchange
-    # (kept behind OCEAN_QUAD_FFT; returns -2 if the swizzle were not a bijection)
-    N = 1024
-    rng = np.random.default_rng(7)
-    x = rng.standard_normal((N, 2)).astype(np.float32)
-    out = np.empty_like(x)
-    assert emul.emul_line_ifft_quad1024(x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0
-    _check(out, x, N)
-
-
-def test_unsupported_size(emul):
-    x = np.zeros((96, 2), np.float32)
-    assert emul.emul_line_ifft(96, x.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p)) == -1

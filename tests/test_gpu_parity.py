@@ -162,11 +162,11 @@ def test_sim_stage(capi, oracle, N):
 
 def packed_fields(fields):
     """The two fields the module transforms instead of ocean.sim's three (include/datum_ocean_hip.h,
-    datum_ocean_debug_rowpass): Hermitian parts of h, hx, hy packed as C = h_H + i hx_H, D = hy_H + 2 sin(theta_x) h_H."""
+    datum_ocean_debug_rowpass): (twice the) Hermitian parts of h, hx, hy packed as C = h_S + i hx_S, D = hy_S + 2 sin(theta_x) h_S."""
     N = fields[0].shape[0]
     idx = (-np.arange(N)) % N
     z = [f[..., 0].astype(np.float64) + 1j * f[..., 1] for f in fields]
-    herm = [0.5 * (f + np.conj(f[idx][:, idx])) for f in z]
+    herm = [f + np.conj(f[idx][:, idx]) for f in z]  # twice the Hermitian part: the column pass folds the 1/2 in
     s2 = 2 * np.sin(2 * np.pi * np.arange(N) / N)[None, :]
     C = herm[0] + 1j * herm[1]
     D = herm[2] + s2 * herm[0]
