@@ -435,7 +435,10 @@ namespace ocean
   {
     static constexpr int E = Plan<N>::E;
     static constexpr int T = Plan<N>::T;
-    static constexpr int PAIRS = (T >= 128) ? 1 : 128 / T;              // row pairs per workgroup
+#ifndef OCEAN_ROW_PAIR_THREADS
+#define OCEAN_ROW_PAIR_THREADS 128   // threads of a row-pass workgroup when one row pair needs fewer (small grids are
+#endif                               // latency-bound: more, smaller workgroups; 512^2 x 1: 9.2 us against 9.9 us with 256)
+    static constexpr int PAIRS = (2 * T >= OCEAN_ROW_PAIR_THREADS) ? 1 : OCEAN_ROW_PAIR_THREADS / (2 * T);   // row pairs per workgroup
     static constexpr int THREADS = 2 * T * PAIRS;
     static constexpr int K = 2;
     static constexpr int PS = 4;
@@ -686,7 +689,7 @@ namespace ocean
 #ifndef OCEAN_COL_FIELDS
 #define OCEAN_COL_FIELDS 2         // fields per barrier phase: 2 (together) or 1 (one after the other, half the LDS)
 #endif
-    static constexpr int WRAW = ((OCEAN_COL_THREADS != 0) ? OCEAN_COL_THREADS : ((T <= 128) ? 512 : 1024)) / T;
+    static constexpr int WRAW = ((OCEAN_COL_THREADS != 0) ? OCEAN_COL_THREADS : ((T < 128) ? 256 : (T == 128) ? 512 : 1024)) / T;    // 512^2 x 1: 8.4 us with 256 threads, 10.1 us with 512
     static constexpr int W = WRAW > 8 ? 8 : (WRAW < 1 ? 1 : WRAW);      // columns per workgroup, one per thread group
     static constexpr int THREADS = W * T;
     static constexpr int K = OCEAN_COL_FIELDS;

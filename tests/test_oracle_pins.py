@@ -241,3 +241,39 @@ def test_reduced_table_is_the_accurate_one(oracle, N):
     assert e_red < 1e-6
     assert e_lit > e_red
     assert np.abs(oracle.weights(N) - oracle.weights(N, reduced=True)).max() < 1e-7 * np.pi * N
+
+
+@pytest.mark.parametrize("N", [64, 128])
+def test_packed_two_transform_identity(oracle, N):
+    # The HIP module transforms two packed fields instead of ocean.sim's three (datum_amd/csrc/ocean_kernels.hip,
+    # "packed step"): C = h_S + i hx_S, D = hy_S + 2 sin(2 pi x / N) h_S with F_S[k] = F[k] + conj(F[-k]).
+    # Pinned here on the CPU against the oracle's three transforms + ocean.map: displacement from Re/Im of the two
+    # transforms (times 1/2), x slope from Im(D) -- no neighbouring columns -- y slope from the heights.
+    e = oracle.EXAMPLE
+    _, h0 = oracle.seed(N, 1234, e["wavescale"], e["waveamplitude"], e["windspeed"], e["winddirection"])
+    phase = np.zeros((N, N), np.float32)
+    for _ in range(5):
+        oracle.update(phase, e["wavescale"], np.float32(1 / 60))
+    ref = oracle.displace(h0, phase.copy(), e["wavescale"], e["choppiness"], w=oracle.weights(N, reduced=True))
+
+    scale = np.float32(1) / np.float32(e["wavescale"])
+    h, hx, hy = (f[..., 0].astype(np.float64) + 1j * f[..., 1] for f in oracle.sim(h0, phase, scale))
+    idx = np.arange(N)
+    neg = (-idx) % N
+    S = lambda F: F + np.conj(F[neg][:, neg])
+    C = S(h) + 1j * S(hx)
+    D = S(hy) + 2 * np.sin(2 * np.pi * idx / N)[None, :] * S(h)
+    Co, Do = (np.fft.ifft2(F) * N * N for F in (C, D))
+    sig = 0.5 * (-1.0) ** (idx[None, :] + idx[:, None])
+    dz = sig * Co.real
+    dx = sig * e["choppiness"] * Co.imag
+    dy = sig * e["choppiness"] * Do.real
+    nx = -sig * Do.imag
+    ny = np.roll(dz, -1, axis=0) - np.roll(dz, 1, axis=0)
+    nz = 4 / (float(scale) * N)
+    inv = 1 / np.sqrt(nx ** 2 + ny ** 2 + nz ** 2)
+    assert np.abs(np.stack([dx, dy, dz], -1) - ref[0][..., :3]).max() < 2e-6 * np.abs(ref[0]).max()
+    assert np.abs(np.stack([nx * inv, ny * inv, nz * inv], -1) - ref[1][..., :3]).max() < 2e-6
+    # the spectra really are Hermitian-packed: the two transforms carry four REAL fields
+    for F in (S(h), S(hx), S(hy)):
+        assert np.abs(np.fft.ifft2(F).imag).max() < 1e-12 * max(1.0, np.abs(F).max())
