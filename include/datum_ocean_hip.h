@@ -161,10 +161,10 @@ int datum_ocean_debug_sim(datum_ocean_t ctx, int cascade, float *h, float *hx, f
 int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *c, float *d);
 
 /* hipEvent timing of the two kernels of datum_ocean_displace on the handle's stream.
- * begin: bracket the kernels of every `stride`-th displace call with events (at most max_samples of them;
- * stride > 1 keeps the recording from perturbing a timed loop: three event records per step cost ~10 % at
- * 100 us per step); end: sync and return the mean kernel durations in milliseconds and the number of
- * displace calls sampled. */
+ * begin: every `stride`-th displace call (at most max_samples of them) launches its two kernels with a start and a
+ * stop event attached to the dispatch itself (hipExtLaunchKernel), i.e. each sampled kernel is timed from its first
+ * to its last workgroup and nothing is inserted between the kernels; end: sync and return the mean kernel durations
+ * in milliseconds and the number of displace calls sampled. */
 int datum_ocean_profile_begin(datum_ocean_t ctx, int max_samples, int stride);
 int datum_ocean_profile_end(datum_ocean_t ctx, double *rowpass_ms, double *colpass_ms, int *steps);
 
