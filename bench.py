@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--resolution", type=int, default=1024)
     ap.add_argument("--cascades", type=int, default=4)
     ap.add_argument("--gather", choices=("batch", "none"), default="batch")
+    ap.add_argument("--spectrum", choices=("fp32", "fp16"), default="fp32",
+                    help="storage of the work spectrum between the two passes (fp16: BASELINE.json configs[4]; arithmetic stays fp32)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
     ap.add_argument("--no-check", action="store_true", help="skip the output sanity check (timing-only ablation builds)")
     return ap.parse_args()
@@ -110,6 +112,7 @@ def main():
 
     # state: this rank's cascades, seeded on the host exactly as seed_ocean does (mt19937(1000 + global index))
     oc = capi.Ocean(N, C, device=local_rank)
+    oc.set_spectrum_format(args.spectrum == "fp16")
     states = []
     for c, g in enumerate(farm.owned_grids(rank, world, C)):
         ws = farm.grid_wavescale(g, C)
@@ -200,8 +203,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{N}x{N} x {C} cascades per GPU, fp32, phase advance + sim + row IFFT + column IFFT + map "
-                            f"(BASELINE.json configs[2])" if (N, C) == (1024, 4) else f"{N}x{N} x {C} cascades per GPU, fp32",
+                "workload": f"{N}x{N} x {C} cascades per GPU, {'fp32 arithmetic, fp16-stored spectrum' if args.spectrum == 'fp16' else 'fp32'}"
+                            + (", phase advance + sim + row IFFT + column IFFT + map (BASELINE.json configs[2])" if (N, C) == (1024, 4) else ""),
                 "resolution": N,
                 "cascades_per_gpu": C,
                 "grids_per_step": C * world,

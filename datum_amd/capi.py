@@ -54,6 +54,7 @@ SYMBOLS = {
     "datum_ocean_bind_maps": (I, [P, P, ctypes.c_size_t]),
     "datum_ocean_maps_device": (I, [P, ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]),
     "datum_ocean_set_cascade": (I, [P, I, F, F]),
+    "datum_ocean_set_spectrum_format": (I, [P, I]),
     "datum_ocean_upload_state": (I, [P, I, P, P]),
     "datum_ocean_read_state": (I, [P, I, P]),
     "datum_ocean_upload_seed": (I, [P, I, P]),
@@ -220,6 +221,10 @@ class Ocean:
         h, hx, hy = (np.empty((self.N, self.N, 2), np.float32) for _ in range(3))
         self._check(self.lib.datum_ocean_debug_sim(self.h, cascade, _ptr(h), _ptr(hx), _ptr(hy)))
         return h, hx, hy
+
+    def set_spectrum_format(self, fp16):
+        """Work spectrum between the passes as IEEE halves (True) or fp32 (False, default)."""
+        self._check(self.lib.datum_ocean_set_spectrum_format(self.h, 1 if fp16 else 0))
 
     def debug_rowpass(self, cascade):
         c, d = (np.empty((self.N, self.N, 2), np.float32) for _ in range(2))

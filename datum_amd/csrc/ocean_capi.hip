@@ -32,7 +32,10 @@ struct datum_ocean_ctx
   float2 *h0 = nullptr;
   float2 *seed = nullptr;             // [cascade][N*N] OceanParams::seed, only when the caller uploads it
   float *phase = nullptr;
-  cd *spec = nullptr;
+  void *spec = nullptr;               // cd[cascades][P], or ch[...] with the fp16 spectrum
+  bool half = false;                  // DATUM_OCEAN_SPECTRUM_FP16
+  bool scaledirty[DATUM_OCEAN_MAX_CASCADES] = {};   // fp16 only: h0 changed since specscale was sized
+  unsigned int *absmax = nullptr;     // device word for ocean_absmax_kernel
   float4 *maps = nullptr;             // the one in use
   float4 *ownmaps = nullptr;
   cf *tw = nullptr;
@@ -107,20 +110,26 @@ namespace
     return a;
   }
 
-  template<int N>
-  hipError_t configure(datum_ocean_ctx *ctx, char const **what)
+  template<int N, bool H16>
+  hipError_t configure_one(char const **what)
   {
     *what = "hipFuncSetAttribute(ocean_rowpass_kernel, MaxDynamicSharedMemorySize)";
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS);
     if (e != hipSuccess)
       return e;
 
     *what = "hipFuncSetAttribute(ocean_colpass_kernel, MaxDynamicSharedMemorySize)";
-    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
-    if (e != hipSuccess)
-      return e;
+    return hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
+  }
 
-    return hipSuccess;
+  template<int N>
+  hipError_t configure(datum_ocean_ctx *ctx, char const **what)
+  {
+    (void)ctx;
+
+    hipError_t e = configure_one<N, false>(what);
+
+    return (e != hipSuccess) ? e : configure_one<N, true>(what);
   }
 
   // ev != nullptr: the dispatch itself carries a start and a stop event (hipExtLaunchKernel), so a sampled kernel is
@@ -138,16 +147,18 @@ namespace
   hipError_t launch_rowpass(datum_ocean_ctx *ctx, StepArgs &a, hipEvent_t *ev)
   {
     void *args[] = { &a };
+    void const *kernel = ctx->half ? reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, true>) : reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>);
 
-    return launch(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), dim3(RowCfg<N>::GROUPS, ctx->cascades), dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream, ev);
+    return launch(kernel, dim3(RowCfg<N>::GROUPS, ctx->cascades), dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream, ev);
   }
 
   template<int N>
   hipError_t launch_colpass(datum_ocean_ctx *ctx, StepArgs &a, hipEvent_t *ev)
   {
     void *args[] = { &a };
+    void const *kernel = ctx->half ? reinterpret_cast<void const*>(&ocean_colpass_kernel<N, true>) : reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>);
 
-    return launch(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), dim3(ColCfg<N>::TILES, ctx->cascades), dim3(ColCfg<N>::THREADS), args, ColCfg<N>::LDS, ctx->stream, ev);
+    return launch(kernel, dim3(ColCfg<N>::TILES, ctx->cascades), dim3(ColCfg<N>::THREADS), args, ColCfg<N>::LDS, ctx->stream, ev);
   }
 
   #define DISPATCH_N(n, expr) \
@@ -245,6 +256,49 @@ namespace
     return DATUM_OCEAN_OK;
   }
 
+  // fp16 work spectrum: the power of two that brings the largest possible row sum under the largest half.
+  // With mu = max |h0| (complex modulus): |h~| <= 2 mu, |h~[k] + conj(h~[-k])| <= 4 mu, |C| <= 8 mu, |D| <= 12 mu,
+  // so no component after the row transform exceeds 12 N mu.  Typical values are ~ sqrt(N) times smaller and
+  // still far above half's denormal range.
+  int size_spectrum_scale(datum_ocean_ctx *ctx)
+  {
+    if (!ctx->half)
+      return DATUM_OCEAN_OK;
+
+    size_t const P = plane(ctx);
+
+    for(int c = 0; c < ctx->cascades; ++c)
+    {
+      if (!ctx->scaledirty[c])
+        continue;
+
+      unsigned int bits = 0;
+
+      HIPCHECK(ctx, hipMemsetAsync(ctx->absmax, 0, sizeof(unsigned int), ctx->stream));
+      hipLaunchKernelGGL(ocean_absmax_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->h0 + c * P, P, ctx->absmax);
+      HIPCHECK(ctx, hipGetLastError());
+      HIPCHECK(ctx, hipMemcpyAsync(&bits, ctx->absmax, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+      float m;
+      memcpy(&m, &bits, sizeof(m));
+
+      if (!(m < 3.0e38f))
+        return fail(ctx, DATUM_OCEAN_EINVAL, "fp16 spectrum: h0 holds a NaN or an infinity");
+
+      double const bound = 12.0 * ctx->N * (1.41421356 * (double)m);
+      int e = (bound > 0) ? (int)std::floor(std::log2(60000.0 / bound)) : 0;
+
+      e = e > 24 ? 24 : (e < -24 ? -24 : e);
+
+      ctx->casc[c].specscale = std::ldexp(1.0f, e);
+      ctx->casc[c].specinv = std::ldexp(1.0f, -e);
+      ctx->scaledirty[c] = false;
+    }
+
+    return DATUM_OCEAN_OK;
+  }
+
   int ensure_scratch(datum_ocean_ctx *ctx)
   {
     if (!ctx->scratch)
@@ -297,6 +351,7 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
   CREATECHECK(hipMalloc(&ctx->h0, cascades * P * sizeof(float2)));
   CREATECHECK(hipMalloc(&ctx->phase, cascades * P * sizeof(float)));
   CREATECHECK(hipMalloc(&ctx->spec, cascades * P * sizeof(cd)));
+  CREATECHECK(hipMalloc(&ctx->absmax, sizeof(unsigned int)));
   CREATECHECK(hipMalloc(&ctx->ownmaps, cascades * 2 * P * sizeof(float4)));
   CREATECHECK(hipMalloc(&ctx->tw, resolution * sizeof(cf)));
   CREATECHECK(hipMalloc(&ctx->omega, (size_t)cascades * (resolution / 2 + 1) * (resolution / 2 + 1) * sizeof(float)));
@@ -330,6 +385,8 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
     ctx->casc[c].scale = 1 / 64.0f;
     ctx->casc[c].choppiness = 1.35f;
     ctx->casc[c].nz = 4 / (ctx->casc[c].scale * resolution);
+    ctx->casc[c].specscale = 1.0f;
+    ctx->casc[c].specinv = 1.0f;
   }
 
   {
@@ -375,6 +432,7 @@ int datum_ocean_destroy(datum_ocean_t ctx)
   (void)hipFree(ctx->seed);
   (void)hipFree(ctx->phase);
   (void)hipFree(ctx->spec);
+  (void)hipFree(ctx->absmax);
   (void)hipFree(ctx->ownmaps);
   (void)hipFree(ctx->tw);
   (void)hipFree(ctx->omega);
@@ -469,6 +527,27 @@ int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, flo
   return DATUM_OCEAN_OK;
 }
 
+int datum_ocean_set_spectrum_format(datum_ocean_t ctx, int format)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_set_spectrum_format: null handle");
+
+  if (format != DATUM_OCEAN_SPECTRUM_FP32 && format != DATUM_OCEAN_SPECTRUM_FP16)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_set_spectrum_format: unknown format");
+
+  ctx->half = (format == DATUM_OCEAN_SPECTRUM_FP16);
+
+  for(int c = 0; c < ctx->cascades; ++c)
+  {
+    ctx->scaledirty[c] = ctx->half;
+
+    if (!ctx->half)
+      ctx->casc[c].specscale = ctx->casc[c].specinv = 1.0f;
+  }
+
+  return DATUM_OCEAN_OK;
+}
+
 int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, float const *phase)
 {
   if (!ctx || !h0)
@@ -506,6 +585,7 @@ int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, fl
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));   // the host buffers are the caller's again
 
   ctx->uploaded[cascade] = true;
+  ctx->scaledirty[cascade] = true;
 
   return DATUM_OCEAN_OK;
 }
@@ -558,6 +638,7 @@ int datum_ocean_rebuild_height(datum_ocean_t ctx, int cascade, float wavescale, 
   size_t const P = plane(ctx);
 
   hipLaunchKernelGGL(ocean_height_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->seed + cascade * P, ctx->h0 + cascade * P, ctx->N, wavescale, waveamplitude, windspeed, windx, windy);
+  ctx->scaledirty[cascade] = true;
   HIPCHECK(ctx, hipGetLastError());
 
   if (!ctx->uploaded[cascade])
@@ -647,6 +728,10 @@ int datum_ocean_displace(datum_ocean_t ctx)
       rc = flush_pending(ctx, fusable(ctx) ? MAX_PENDING : 0);
   }
 
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  rc = size_spectrum_scale(ctx);
   if (rc != DATUM_OCEAN_OK)
     return rc;
 
@@ -887,7 +972,10 @@ int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *c, float *d
 
   size_t const P = plane(ctx);
 
-  hipLaunchKernelGGL(ocean_unpack_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->spec + (size_t)cascade * P, ctx->N, ctx->scratch, ctx->scratch + P);
+  if (ctx->half)
+    hipLaunchKernelGGL(ocean_unpack_kernel<true>, dim3(1024), dim3(256), 0, ctx->stream, static_cast<ch const*>(ctx->spec) + (size_t)cascade * P, ctx->N, ctx->casc[cascade].specinv, ctx->scratch, ctx->scratch + P);
+  else
+    hipLaunchKernelGGL(ocean_unpack_kernel<false>, dim3(1024), dim3(256), 0, ctx->stream, static_cast<cd const*>(ctx->spec) + (size_t)cascade * P, ctx->N, 1.0f, ctx->scratch, ctx->scratch + P);
   HIPCHECK(ctx, hipGetLastError());
   HIPCHECK(ctx, hipMemcpyAsync(c, ctx->scratch, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHECK(ctx, hipMemcpyAsync(d, ctx->scratch + P, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
@@ -959,8 +1047,10 @@ int datum_ocean_algorithmic_bytes(datum_ocean_t ctx, double *rowpass_bytes, doub
   // the ALGORITHM's bytes as the reference states it, three transforms (bench.py's roofline):
   // h0 8 + phase in 4 + phase out 4 + spectrum out 24 | spectrum in 24 + two RGBA32F layers 32.
   // The packed step moves 16 instead of 24 spectrum bytes each way (32 + 48 = 80 B/pt of HBM traffic).
-  if (rowpass_bytes) *rowpass_bytes = 40.0 * pts;
-  if (colpass_bytes) *colpass_bytes = 56.0 * pts;
+  // fp16-stored spectrum: 4 + 4 + 4 + 12 | 12 + 32 = 68 B/pt; this build keeps h0 in fp32 and
+  // moves 8 + 4 + 4 + 8 | 8 + 32 = 64 B/pt.
+  if (rowpass_bytes) *rowpass_bytes = (ctx->half ? 24.0 : 40.0) * pts;
+  if (colpass_bytes) *colpass_bytes = (ctx->half ? 44.0 : 56.0) * pts;
 
   return DATUM_OCEAN_OK;
 }

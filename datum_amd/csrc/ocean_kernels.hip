@@ -33,19 +33,28 @@ namespace ocean
 
   typedef float4 cd;    // (C.re, C.im, D.re, D.im) of one grid point: the two packed fields of the work spectrum
 
+  // the same four numbers as IEEE halves, 8 bytes (BASELINE.json configs[4]: spectrum stored fp16, arithmetic fp32)
+  typedef _Float16 half4_ __attribute__((ext_vector_type(4)));
+  struct ch { half4_ v; };
+
+  template<bool H16> struct SpecValue { typedef cd type; };
+  template<> struct SpecValue<true> { typedef ch type; };
+
   struct CascadeConst
   {
     float wavescale;     // OceanParams::wavescale                 (update_ocean, ocean.cpp:225-229)
     float scale;         // OceanSet::scale = 1 / wavescale        (ocean.cpp:743)
     float choppiness;    // OceanSet::choppiness                   (ocean.cpp:744)
     float nz;            // 4 / (scale * N)                        (ocean.map.comp:77)
+    float specscale;     // fp16 work spectrum only: power of two the row pass multiplies (C, D) by before rounding to half
+    float specinv;       // ... and its reciprocal, folded into the column pass's sign factor (1 for the fp32 spectrum)
   };
 
   struct StepArgs
   {
     float2 const *h0;    // [cascade][N*N]       OceanSet::h0
     float *phase;        // [cascade][N*N]       OceanSet::phase
-    cd *spec;            // [cascade][N*N]       work spectrum (replaces Spectrum::h, hx, hy), blocked layout
+    void *spec;          // [cascade][N*N]       work spectrum (replaces Spectrum::h, hx, hy), blocked layout: cd, or ch (fp16 variant)
     float4 *maps;        // [cascade][2][N*N]    displacementmap, 2 layers RGBA32F
     cf const *tw;        // [N]                  exp(+2 pi i k / N)
     float const *omega;  // [cascade][(N/2+1)^2] dispersion(k) by (|m - N/2|, |n - N/2|)
@@ -481,7 +490,7 @@ namespace ocean
     }
   }
 
-  template<int N>
+  template<int N, bool H16>
   __global__ void __launch_bounds__(RowCfg<N>::THREADS) ocean_rowpass_kernel(StepArgs a)
   {
     typedef Plan<N> P;
@@ -533,7 +542,9 @@ namespace ocean
 
     __amdgpu_buffer_rsrc_t rphase = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
     __amdgpu_buffer_rsrc_t rh0 = make_rsrc(h0, plane * sizeof(float2));
-    __amdgpu_buffer_rsrc_t rspec = make_rsrc(a.spec + cascade * plane, plane * sizeof(cd));
+    typedef typename SpecValue<H16>::type SV;
+
+    __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV*>(a.spec) + cascade * plane, plane * sizeof(SV));
 
     bool const advance = a.ndt > 0;
 
@@ -672,7 +683,15 @@ namespace ocean
 #ifdef OCEAN_ABLATE_ROWSTORE
       if (v[0][s].x == 123456.789f)
 #endif
-      buf_store_f32x4(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
+      if constexpr (H16)
+      {
+        // round to nearest even; the host picks specscale so that no row sum can overflow (ocean_capi: spectrum_scale)
+        half4_ const hv = { (_Float16)(v[0][s].x * cc.specscale), (_Float16)(v[0][s].y * cc.specscale), (_Float16)(v[1][s].x * cc.specscale), (_Float16)(v[1][s].y * cc.specscale) };
+
+        buf_store_cf(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
+      }
+      else
+        buf_store_f32x4(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
     }
 
     OCEAN_STAMP(5);
@@ -716,7 +735,7 @@ namespace ocean
   // One tile per workgroup.  (A persistent variant -- workgroups walking a run of tiles, the next tile's values
   // requested ahead and the map stores draining behind -- was measured 15 % slower: this pass runs at the rate the
   // memory system moves its 48 B/pt, and queueing more requests per workgroup only delays the first ones.)
-  template<int N>
+  template<int N, bool H16>
   __global__ void __launch_bounds__(ColCfg<N>::THREADS) ocean_colpass_kernel(StepArgs a)
   {
     typedef Plan<N> P;
@@ -755,7 +774,9 @@ namespace ocean
 
     static_assert(T % 8 == 0, "slots must be whole 8-row blocks apart");
 
-    __amdgpu_buffer_rsrc_t rspec = make_rsrc(a.spec + cascade * plane, plane * sizeof(cd));
+    typedef typename SpecValue<H16>::type SV;
+
+    __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV const*>(a.spec) + cascade * plane, plane * sizeof(SV));
     __amdgpu_buffer_rsrc_t rmaps = make_rsrc(a.maps + (size_t)cascade * 2 * plane, 2 * plane * sizeof(float4));
 
 #ifdef OCEAN_STAMPS
@@ -772,7 +793,14 @@ namespace ocean
 #ifdef OCEAN_ABLATE_COLLOAD
       q[s] = make_float4(0.01f * (float)((t + s) & 31), 0.02f * (float)s, 0.03f, 0.01f * (float)cp);
 #else
-      q[s] = buf_load_f32x4(rspec, (int)blocked<N>(t, x) * 16, DBI * s * 16);
+      if constexpr (H16)
+      {
+        half4_ const hv = __builtin_bit_cast(half4_, buf_load_cf(rspec, (int)blocked<N>(t, x) * 8, DBI * s * 8));
+
+        q[s] = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
+      }
+      else
+        q[s] = buf_load_f32x4(rspec, (int)blocked<N>(t, x) * 16, DBI * s * 16);
 #endif
     }
 
@@ -818,7 +846,7 @@ namespace ocean
 
     // (-1)^(x+y) of map.comp:60; a thread's rows differ by even amounts
     // times the 1/2 of the Hermitian parts, which the row pass leaves out
-    float const sig = ((x + t) & 1) ? -0.5f : 0.5f;
+    float const sig = (((x + t) & 1) ? -0.5f : 0.5f) * cc.specinv;
     float const sigchop = sig * cc.choppiness;
 
     // the transform lines are free after the last barrier of fft_lines: heights of this column for the y slope
@@ -863,7 +891,8 @@ namespace ocean
   }
 
   // blocked packed spectrum -> two row-major complex planes (datum_ocean_debug_rowpass)
-  __global__ void ocean_unpack_kernel(cd const *spec, int N, cf *c, cf *d)
+  template<bool H16>
+  __global__ void ocean_unpack_kernel(void const *spec, int N, float specinv, cf *c, cf *d)
   {
     size_t const plane = (size_t)N * N;
 
@@ -871,11 +900,42 @@ namespace ocean
     {
       int y = (int)(i / N), x = (int)(i % N);
 
-      cd v = spec[((size_t)((y >> 3) * (N / 8) + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7)];
+      size_t const at = ((size_t)((y >> 3) * (N / 8) + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7);
+
+      float4 v;
+
+      if constexpr (H16)
+      {
+        half4_ hv = static_cast<ch const*>(spec)[at].v;
+        v = make_float4((float)hv.x * specinv, (float)hv.y * specinv, (float)hv.z * specinv, (float)hv.w * specinv);
+      }
+      else
+        v = static_cast<cd const*>(spec)[at];
 
       c[i] = cf{ v.x, v.y };
       d[i] = cf{ v.z, v.w };
     }
+  }
+
+  // largest |component| of a cascade's h0 (bit pattern of a non-negative float orders like the float): sizes the
+  // fp16 spectrum's scale
+  __global__ void ocean_absmax_kernel(float2 const *h0, size_t count, unsigned int *result)
+  {
+    float m = 0.0f;
+
+    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    {
+      float2 v = h0[i];
+      float a = fmaxf(fabsf(v.x), fabsf(v.y));
+
+      m = (a == a) ? fmaxf(m, a) : __builtin_inff();     // a NaN must not hide
+    }
+
+    for(int o = 32; o > 0; o >>= 1)
+      m = fmaxf(m, __shfl_xor(m, o));
+
+    if ((threadIdx.x & 63) == 0)
+      atomicMax(result, __float_as_uint(m));
   }
 
   //|---------------------- spectrum rebuild (lerp_ocean_waves) ----------------

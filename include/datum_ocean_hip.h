@@ -88,6 +88,14 @@ int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, flo
 
 /* h0 = OceanParams::height, N*N*2 floats (ocean.cpp:748); phase = OceanParams::phase, N*N floats
  * (ocean.cpp:749) or NULL for all-zero (seed_ocean, ocean.cpp:144).  Host pointers. */
+/* Extension (BASELINE.json configs[4]): how the work spectrum between the two passes is stored.  FP32 (default): 16 B
+ * per point.  FP16: 8 B per point, arithmetic stays fp32; the values are scaled by a power of two sized from max |h0|
+ * so that no row sum can overflow a half.  Displacement error then ~5e-4 relative to the largest displacement
+ * (tests state 2e-3).  Takes effect at the next datum_ocean_displace. */
+#define DATUM_OCEAN_SPECTRUM_FP32 0
+#define DATUM_OCEAN_SPECTRUM_FP16 1
+int datum_ocean_set_spectrum_format(datum_ocean_t ctx, int format);
+
 int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, float const *phase);
 int datum_ocean_read_state(datum_ocean_t ctx, int cascade, float *phase);
 

@@ -412,3 +412,61 @@ def test_bound_maps_and_caller_stream(capi, oracle, torch):
         assert np.array_equal(buf.cpu().numpy().reshape(2, N, N, 4), own)
         oc.bind_maps(0, 0)
         oc.set_stream(None)
+
+
+@pytest.mark.parametrize("N", [256, 1024])
+def test_fp16_spectrum_against_oracle(capi, oracle, N):
+    # BASELINE.json configs[4]: work spectrum stored as IEEE halves (8 B/pt between the passes), arithmetic fp32.
+    # Tolerance re-stated for fp16: each stored value carries a relative error <= 2^-11 (round to nearest; the scale is
+    # sized so that nothing overflows), and a displacement is a sum of N of them with random signs, so the error is
+    # ~ 2^-11 of the rms displacement: RMSE < 2e-3 of the largest |displacement|, unit normals within 1e-2.
+    # The phase state does not pass through the spectrum: still bit-exact.
+    p = oracle.EXAMPLE
+    h0 = make_state(oracle, N, 1000)
+    with capi.Ocean(N, 1) as oc:
+        oc.set_spectrum_format(True)
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        oc.upload_state(0, h0)
+        for _ in range(3):
+            oc.update(DT)
+            oc.displace()
+        got = oc.read_maps(0)
+        gphase = oc.read_state(0)
+        oc.set_spectrum_format(False)      # back to fp32 on the same handle
+        oc.displace()
+        exact = oc.read_maps(0)
+    phase = np.zeros((N, N), np.float32)
+    for _ in range(3):
+        oracle.update(phase, p["wavescale"], DT)
+    assert np.array_equal(gphase, phase)
+    ref = oracle.displace(h0, phase.copy(), p["wavescale"], p["choppiness"], w=oracle.weights(N, reduced=True))
+    scale = float(np.abs(ref[0][..., :3]).max())
+    assert rmse(exact[0][..., :3], ref[0][..., :3]) < 1e-5
+    e = rmse(got[0][..., :3], ref[0][..., :3])
+    assert 1e-7 * scale < e < 2e-3 * scale        # really went through halves, and within the stated tolerance
+    assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 1e-2
+    assert np.all(got[..., 3] == 0)
+
+
+def test_fp16_spectrum_4096(capi):
+    # the stress size of configs[4]: fp16 against this module's own fp32 result on the same state, plus the properties
+    # that do not need an oracle (no overflow / NaN at the largest size, w components zero)
+    from datum_amd import host_api
+    N = 4096
+    p = host_api.OceanParams(N, **host_api.EXAMPLE_TUNABLES)
+    p.seed_ocean(1000)
+    h0 = p.height.copy()
+    with capi.Ocean(N, 1) as oc:
+        oc.set_cascade(0, host_api.EXAMPLE_TUNABLES["wavescale"], 1.35)
+        oc.upload_state(0, h0)
+        oc.update(DT)
+        oc.displace()
+        exact = oc.read_maps(0)
+        oc.set_spectrum_format(True)
+        oc.displace()
+        got = oc.read_maps(0)
+    assert np.isfinite(got).all()
+    scale = float(np.abs(exact[0][..., :3]).max())
+    assert rmse(got[0][..., :3], exact[0][..., :3]) < 2e-3 * scale
+    assert np.abs(got[1][..., :3] - exact[1][..., :3]).max() < 2e-2
+    assert np.all(got[..., 3] == 0)

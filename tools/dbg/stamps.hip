@@ -25,12 +25,12 @@ int main() {
     std::vector<float> om((size_t)C*(N/2+1)*(N/2+1), 1.0f); CK(hipMemcpy(omega, om.data(), om.size()*4, hipMemcpyHostToDevice));
     std::vector<cf> t(N); for (int k=0;k<N;++k) t[k] = cf{(float)cos(2*M_PI*k/N),(float)sin(2*M_PI*k/N)}; CK(hipMemcpy(tw, t.data(), N*8, hipMemcpyHostToDevice)); }
   a.h0=h0; a.phase=phase; a.spec=spec; a.maps=maps; a.tw=tw; a.omega=omega; a.ndt=1; a.cascades=C; a.dt[0]=1.f/60; a.stamps=stamps;
-  for (int c=0;c<DATUM_OCEAN_MAX_CASCADES;++c) a.casc[c] = CascadeConst{22.f, 1/22.f, 1.35f, 4/(N/22.f)};
-  CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS));
-  CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS));
+  for (int c=0;c<DATUM_OCEAN_MAX_CASCADES;++c) a.casc[c] = CascadeConst{22.f, 1/22.f, 1.35f, 4/(N/22.f), 1.f, 1.f};
+  CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS));
+  CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS));
   for (int it = 0; it < 5; ++it) {
-    hipLaunchKernelGGL(ocean_rowpass_kernel<N>, dim3(RowCfg<N>::GROUPS, C), dim3(RowCfg<N>::THREADS), RowCfg<N>::LDS, 0, a);
-    hipLaunchKernelGGL(ocean_colpass_kernel<N>, dim3(ColCfg<N>::TILES, C), dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, 0, a);
+    hipLaunchKernelGGL(ocean_rowpass_kernel<N, false>, dim3(RowCfg<N>::GROUPS, C), dim3(RowCfg<N>::THREADS), RowCfg<N>::LDS, 0, a);
+    hipLaunchKernelGGL(ocean_colpass_kernel<N, false>, dim3(ColCfg<N>::TILES, C), dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, 0, a);
   }
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> st(nst); CK(hipMemcpy(st.data(), stamps, nst*8, hipMemcpyDeviceToHost));
