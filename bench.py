@@ -187,7 +187,7 @@ def main():
         step_ach = (row_b + col_b) / ((row_ms + col_ms) * 1e-3) / 1e9 if row_ms + col_ms > 0 else 0.0
 
         kernel_name = f"ocean_{dom[0]}_kernel<{N}>"
-        traffic, traffic_source = measured_traffic(kernel_name, f"{N}x{N} x {C} cascades")
+        traffic, traffic_source = measured_traffic(kernel_name, f"{N}x{N} x {C} cascades") if args.spectrum == "fp32" else (None, None)
 
         line = {
             "metric": "ocean grids/sec (N x N displacement step)",
