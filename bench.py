@@ -34,7 +34,7 @@ DT = np.float32(1.0 / 60.0)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--resolution", type=int, default=1024)
     ap.add_argument("--cascades", type=int, default=4)
@@ -122,6 +122,8 @@ def main():
         oc.upload_state(c, p.height)
         if rank == 0 and world == 1:
             states.append((p.height.copy(), ws))
+        if c == 0:
+            genset = p.oceanset()          # the OceanSet header of render_ocean_surface for the example camera
         del p
 
     # maps land in a torch tensor so that RCCL can gather them in place; kernels run on torch's stream
@@ -166,6 +168,25 @@ def main():
     elapsed = time.perf_counter() - t0
 
     row_ms, col_ms, nprof = oc.profile_end()
+
+    # ocean.gen (reported separately, as vertices/s): the 1024 x 1024 projected-grid mesh of the example
+    # (examples/ocean/ocean.cpp:59) from cascade 0's maps, outside the timed region above
+    gen = None
+    if rank == 0:
+        sx = sy = 1024
+        verts = torch.empty(sx * sy * 12, dtype=torch.float32, device=dev)
+        g0, g1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+        for _ in range(3):
+            oc.gen(0, genset, sx, sy, verts.data_ptr())
+        g0.record(stream)
+        for _ in range(20):
+            oc.gen(0, genset, sx, sy, verts.data_ptr())
+        g1.record(stream)
+        torch.cuda.synchronize(dev)
+        gms = g0.elapsed_time(g1) / 20
+        gbytes = 48.0 * sx * sy + 32.0 * N * N
+        gen = {"mesh": f"{sx}x{sy}", "ms": gms, "vertices_per_s": sx * sy / (gms * 1e-3), "GBps": gbytes / (gms * 1e-3) / 1e9,
+               "bytes": gbytes, "finite": bool(torch.isfinite(verts).all())}
     compute_ms = ev0.elapsed_time(ev1)
     gather_ms = ev1.elapsed_time(ev2) if gathered is not None else 0.0
 
@@ -230,6 +251,7 @@ def main():
             },
             "compute_ms": compute_ms,
             "gather_ms": gather_ms,
+            "gen": gen,
             "value_compute_only": grids / (compute_ms * 1e-3) if compute_ms > 0 else None,
         }
 

@@ -773,6 +773,7 @@ int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, 
 
   GenArgs g;
   g.set = *set;
+  g.frame = make_gen_frame(*set);
   g.layer0 = ctx->maps + (size_t)cascade * 2 * plane(ctx);
   g.layer1 = g.layer0 + plane(ctx);
   g.N = ctx->N;

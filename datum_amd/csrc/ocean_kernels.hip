@@ -1031,9 +1031,22 @@ namespace ocean
 
   //|---------------------- ocean.gen -----------------------------------------
 
+  // per-launch constants of ocean.gen that do not depend on the vertex (gen.comp:75-79,93-99), evaluated once on the
+  // host in the shader's operation order instead of once per thread (gfx950 has no scalar float unit)
+  struct GenFrame
+  {
+    float camerapos[3];
+    float cameraheight;
+    float margin;
+    float frequency;
+    float qi;
+    float phi;
+  };
+
   struct GenArgs
   {
     datum_ocean_set set;
+    GenFrame frame;
     float4 const *layer0;
     float4 const *layer1;
     int N;
@@ -1044,11 +1057,17 @@ namespace ocean
 
   struct f3 { float x, y, z; };
 
-  __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
-  __device__ __forceinline__ f3 operator*(float s, f3 a) { return { s * a.x, s * a.y, s * a.z }; }
-  __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-  __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
-  __device__ __forceinline__ f3 normalize3(f3 a) { float l = sqrtf(dot3(a, a)); return { a.x / l, a.y / l, a.z / l }; }
+  __host__ __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+  __host__ __device__ __forceinline__ f3 operator*(float s, f3 a) { return { s * a.x, s * a.y, s * a.z }; }
+  __host__ __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+  __host__ __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+
+  // a / |a|: IEEE square root and divisions, as the oracle does it -- for the view ray, whose direction decides where a
+  // grazing ray meets the plane (one ulp there moves horizon vertices by whole texels)
+  __device__ __forceinline__ f3 normalize3_exact(f3 a) { float l = sqrtf(dot3(a, a)); return { a.x / l, a.y / l, a.z / l }; }
+
+  // a / |a| with the hardware reciprocal square root (1 ulp): the shading frame, where errors are not amplified
+  __device__ __forceinline__ f3 normalize3(f3 a) { float inv = __builtin_amdgcn_rsqf(dot3(a, a)); return { a.x * inv, a.y * inv, a.z * inv }; }
 
   // rotate v by the unit quaternion q = (w, x, y, z)   (data/transform.inc:32-37)
   __device__ __forceinline__ f3 rotate(float const (&q)[4], f3 v)
@@ -1059,8 +1078,33 @@ namespace ocean
     return v + q[0] * tt + cross3(u, tt);
   }
 
-  // texture(sampler2DArray, REPEAT, linear, lod 0) at normalised (u, v): texel centres at (i + 0.5) / N
-  __device__ __forceinline__ f3 sample_repeat(float4 const *layer, int N, float u, float v)
+  inline GenFrame make_gen_frame(datum_ocean_set const &p)
+  {
+    GenFrame f;
+
+    // camerapos = 2 * (dual * conjugate(real)).yzw   (gen.comp:75, transform.inc:13-28)
+    float rw = p.camera_real[0], ri = -p.camera_real[1], rj = -p.camera_real[2], rk = -p.camera_real[3];
+    float dw = p.camera_dual[0], di = p.camera_dual[1], dj = p.camera_dual[2], dk = p.camera_dual[3];
+
+    f.camerapos[0] = 2 * (dw * ri + di * rw + dj * rk - dk * rj);
+    f.camerapos[1] = 2 * (dw * rj + dj * rw + dk * ri - di * rk);
+    f.camerapos[2] = 2 * (dw * rk + dk * rw + di * rj - dj * ri);
+
+    f.cameraheight = (p.plane[0] * f.camerapos[0] + p.plane[1] * f.camerapos[1] + p.plane[2] * f.camerapos[2]) + p.plane[3];
+    f.margin = 1 + sqrtf((2 * p.swellamplitude + 0.5f) / f.cameraheight);
+
+    // Gerstner swell constants (gen.comp:93-99)
+    f.frequency = 2 * 3.14159265358979323846f / p.swelllength;
+    f.qi = p.swellsteepness / (f.frequency * p.swellamplitude * 4 + 1e-6f);
+    f.phi = f.frequency * p.swellamplitude;
+
+
+    return f;
+  }
+
+  // texture(sampler2DArray, REPEAT, linear, lod 0) of both layers at normalised (u, v): texel centres at (i + 0.5) / N.
+  // N is a power of two: REPEAT is a mask (two's complement makes it right for negative texel indices too).
+  __device__ __forceinline__ void sample_repeat2(float4 const *layer0, float4 const *layer1, int N, float u, float v, f3 &s0, f3 &s1)
   {
     float fx = u * (float)N - 0.5f;
     float fy = v * (float)N - 0.5f;
@@ -1071,23 +1115,25 @@ namespace ocean
     float ax = fx - flx;
     float ay = fy - fly;
 
-    long long ix = (long long)flx, iy = (long long)fly;
-
-    int i0 = (int)(((ix % N) + N) % N);
-    int j0 = (int)(((iy % N) + N) % N);
+    int i0 = (int)flx & (N - 1);
+    int j0 = (int)fly & (N - 1);
     int i1 = (i0 + 1) & (N - 1);
     int j1 = (j0 + 1) & (N - 1);
 
-    float4 t00 = layer[(size_t)j0 * N + i0];
-    float4 t10 = layer[(size_t)j0 * N + i1];
-    float4 t01 = layer[(size_t)j1 * N + i0];
-    float4 t11 = layer[(size_t)j1 * N + i1];
+    int const o00 = j0 * N + i0, o10 = j0 * N + i1, o01 = j1 * N + i0, o11 = j1 * N + i1;
+
+    float4 a00 = layer0[o00], a10 = layer0[o10], a01 = layer0[o01], a11 = layer0[o11];
+    float4 b00 = layer1[o00], b10 = layer1[o10], b01 = layer1[o01], b11 = layer1[o11];
 
     float w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
 
-    return { w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x,
-             w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
-             w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z };
+    s0 = { w00 * a00.x + w10 * a10.x + w01 * a01.x + w11 * a11.x,
+           w00 * a00.y + w10 * a10.y + w01 * a01.y + w11 * a11.y,
+           w00 * a00.z + w10 * a10.z + w01 * a01.z + w11 * a11.z };
+
+    s1 = { w00 * b00.x + w10 * b10.x + w01 * b01.x + w11 * b11.x,
+           w00 * b00.y + w10 * b10.y + w01 * b01.y + w11 * b11.y,
+           w00 * b00.z + w10 * b10.z + w01 * b01.z + w11 * b11.z };
   }
 
   // data/ocean.gen.comp:67-137, one thread per mesh vertex
@@ -1100,25 +1146,16 @@ namespace ocean
       return;
 
     datum_ocean_set const &p = g.set;
+    GenFrame const &f = g.frame;
 
     size_t const index = (size_t)yy * g.sizex + xx;
 
-    // camerapos = 2 * (dual * conjugate(real)).yzw   (gen.comp:75, transform.inc:13-28)
-    float rw = p.camera_real[0], ri = -p.camera_real[1], rj = -p.camera_real[2], rk = -p.camera_real[3];
-    float dw = p.camera_dual[0], di = p.camera_dual[1], dj = p.camera_dual[2], dk = p.camera_dual[3];
+    f3 const camerapos = { f.camerapos[0], f.camerapos[1], f.camerapos[2] };
+    f3 const planen = { p.plane[0], p.plane[1], p.plane[2] };
 
-    f3 camerapos = { 2 * (dw * ri + di * rw + dj * rk - dk * rj),
-                     2 * (dw * rj + dj * rw + dk * ri - di * rk),
-                     2 * (dw * rk + dk * rw + di * rj - dj * ri) };
-
-    f3 planen = { p.plane[0], p.plane[1], p.plane[2] };
-
-    float cameraheight = dot3(planen, camerapos) + p.plane[3];
-
-    float margin = 1 + sqrtf((2 * p.swellamplitude + 0.5f) / cameraheight);
-
-    float u = (2 * (float)xx / (float)(g.sizex - 1) - 1) * margin;
-    float v = (1 - 2 * (float)yy / (float)(g.sizey - 1)) * margin;
+    // exactly the shader's expressions up to the base position: near the horizon the plane hit is ill-conditioned
+    float u = (2 * (float)xx / (float)(g.sizex - 1) - 1) * f.margin;
+    float v = (1 - 2 * (float)yy / (float)(g.sizey - 1)) * f.margin;
 
     float const *ip = p.invproj;
 
@@ -1126,30 +1163,30 @@ namespace ocean
                    ip[4] * u + ip[5] * v + ip[6] * 0.0f + ip[7] * 1.0f,
                    ip[8] * u + ip[9] * v + ip[10] * 0.0f + ip[11] * 1.0f };
 
-    f3 worlddir = rotate(p.camera_real, normalize3(viewvec));
+    f3 worlddir = rotate(p.camera_real, normalize3_exact(viewvec));
 
     float costheta = dot3(worlddir, f3{ -planen.x, -planen.y, -planen.z });
 
-    float dist = (costheta > 0) ? cameraheight / costheta : 1e6f;
+    float dist = (costheta > 0) ? f.cameraheight / costheta : 1e6f;
 
     f3 baseposition = { camerapos.x + dist * worlddir.x, camerapos.y + dist * worlddir.y, -p.plane[3] };
 
     // Gerstner swell (gen.comp:93-109)
-    float amplitude = p.swellamplitude;
-    float frequency = 2 * 3.14159265358979323846f / p.swelllength;
-    float dirx = p.swelldirection[0], diry = p.swelldirection[1];
-    float qi = p.swellsteepness / (frequency * amplitude * 4 + 1e-6f);
+    float const amplitude = p.swellamplitude;
+    float const dirx = p.swelldirection[0], diry = p.swelldirection[1];
+    float const qi = f.qi, phi = f.phi;
 
-    float phi = frequency * amplitude;
-    float theta = frequency * (dirx * baseposition.x + diry * baseposition.y) + p.swellphase;
+    float theta = f.frequency * (dirx * baseposition.x + diry * baseposition.y) + p.swellphase;
 
     float st, ct;
-    sincosf(theta, &st, &ct);
+    sincosf(theta, &st, &ct);        // theta reaches 1e5 at the horizon: full-range reduction
 
     f3 position = { baseposition.x + qi * amplitude * dirx * ct, baseposition.y + qi * amplitude * diry * ct, baseposition.z + amplitude * st };
 
-    f3 normal = { phi * dirx * ct / 6, phi * diry * ct / 6, qi * phi * st };
-    f3 tangent = { qi * phi * dirx * dirx * st, qi * phi * diry * dirx * st, phi * dirx * ct / 6 };
+    float const sixth = 1.0f / 6;
+
+    f3 normal = { phi * dirx * ct * sixth, phi * diry * ct * sixth, qi * phi * st };
+    f3 tangent = { qi * phi * dirx * dirx * st, qi * phi * diry * dirx * st, phi * dirx * ct * sixth };
 
     f3 tbn2 = normalize3(f3{ -normal.x, -normal.y, 1 - normal.z });
     f3 tbn0 = normalize3(f3{ 1 - tangent.x, -tangent.y, tangent.z });
@@ -1158,12 +1195,12 @@ namespace ocean
     float tu = position.x * p.scale;
     float tv = position.y * p.scale;
 
-    f3 displacement = sample_repeat(g.layer0, g.N, tu, tv);
-    f3 dn = sample_repeat(g.layer1, g.N, tu, tv);
+    f3 displacement, dn;
+    sample_repeat2(g.layer0, g.layer1, g.N, tu, tv, displacement, dn);
 
     float cl = dist * p.smoothing - 0.35f;
     cl = fminf(fmaxf(cl, 0.0f), 1.0f);
-    float smoothing = powf(cl, 0.2f);
+    float smoothing = __builtin_amdgcn_exp2f(0.2f * __builtin_amdgcn_logf(cl));   // pow(cl, 0.2): 0 -> 0, 1 -> 1
 
     f3 tn = dn.x * tbn0 + dn.y * tbn1 + dn.z * tbn2;
 
