@@ -4,13 +4,13 @@
 using namespace ocean;
 template<int N> void probe() {
   int nb = -1;
-  hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS);
-  hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>), RowCfg<N>::THREADS, RowCfg<N>::LDS);
-  hipFuncAttributes fa; hipFuncGetAttributes(&fa, reinterpret_cast<void const*>(&ocean_rowpass_kernel<N>));
+  hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS);
+  hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>), RowCfg<N>::THREADS, RowCfg<N>::LDS);
+  hipFuncAttributes fa; hipFuncGetAttributes(&fa, reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>));
   printf("N=%d rowpass: threads %d lds %zu regs %d -> blocks/CU %d\n", N, RowCfg<N>::THREADS, RowCfg<N>::LDS, fa.numRegs, nb);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<void const*>(&ocean_colpass_kernel<N>), ColCfg<N>::THREADS, ColCfg<N>::LDS);
-  hipFuncGetAttributes(&fa, reinterpret_cast<void const*>(&ocean_colpass_kernel<N>));
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>), ColCfg<N>::THREADS, ColCfg<N>::LDS);
+  hipFuncGetAttributes(&fa, reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>));
   printf("N=%d colpass: threads %d lds %zu regs %d -> blocks/CU %d\n", N, ColCfg<N>::THREADS, ColCfg<N>::LDS, fa.numRegs, nb);
 }
 int main(){ probe<512>(); probe<1024>(); probe<2048>(); return 0; }
