@@ -117,6 +117,13 @@ namespace ocean
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0));
   }
 
+  // the same with a cache-policy operand (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+  template<int AUX>
+  __device__ __forceinline__ float4 buf_load_f32x4_aux(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, AUX));
+  }
+
   // Stores: the per-access part goes into the VGPR offset (one v_add_u32), not into an SGPR.  A 128-bit buffer
   // store with an SGPR offset was observed on gfx950 / ROCm 7.2 to store stale x, y components in the last lanes of
   // each 16-lane group when the next VALU instruction rewrote its data registers: hipcc enforces the "VALU write of
@@ -124,6 +131,12 @@ namespace ocean
   __device__ __forceinline__ void buf_store_f32(float v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
   {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voffset + soffset, 0, 0);
+  }
+
+  template<int AUX>
+  __device__ __forceinline__ void buf_store_f32_aux(float v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voffset + soffset, 0, AUX);
   }
 
   __device__ __forceinline__ void buf_store_cf(cf v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
@@ -135,6 +148,28 @@ namespace ocean
   {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, voffset + soffset, 0, 0);
   }
+
+  template<int AUX>
+  __device__ __forceinline__ void buf_store_f32x4_aux(float4 v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, voffset + soffset, 0, AUX);
+  }
+
+// measured at 1024^2 x 4: map stores written through (sc0 sc1) leave the XCD's L2 to the spectrum lines that neighbouring
+// tiles share: column pass 36.7 -> 35.1 us; nt on the same stores 44.5 us, nt on the spectrum loads 44.4 us
+#ifndef OCEAN_MAP_STORE_AUX
+#define OCEAN_MAP_STORE_AUX 17
+#endif
+// (row pass with both of its store streams written through: 29.4 -> 28.4 us; either one alone: no change)
+#ifndef OCEAN_PHASE_STORE_AUX
+#define OCEAN_PHASE_STORE_AUX 17
+#endif
+#ifndef OCEAN_SPEC_STORE_AUX
+#define OCEAN_SPEC_STORE_AUX 17
+#endif
+#ifndef OCEAN_SPEC_LOAD_AUX
+#define OCEAN_SPEC_LOAD_AUX 0
+#endif
 
   //|---------------------- update_ocean --------------------------------------
 
@@ -614,7 +649,7 @@ namespace ocean
 #ifdef OCEAN_ABLATE_ROWSTORE
         if (ph[s] == 123456.789f)
 #endif
-        buf_store_f32(ph[s], rphase, (y * N + t) * 4, T * s * 4);
+        buf_store_f32_aux<OCEAN_PHASE_STORE_AUX>(ph[s], rphase, (y * N + t) * 4, T * s * 4);
       }
     }
 
@@ -691,7 +726,7 @@ namespace ocean
         buf_store_cf(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
       }
       else
-        buf_store_f32x4(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
+        buf_store_f32x4_aux<OCEAN_SPEC_STORE_AUX>(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
     }
 
     OCEAN_STAMP(5);
@@ -800,7 +835,7 @@ namespace ocean
         q[s] = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
       }
       else
-        q[s] = buf_load_f32x4(rspec, (int)blocked<N>(t, x) * 16, DBI * s * 16);
+        q[s] = buf_load_f32x4_aux<OCEAN_SPEC_LOAD_AUX>(rspec, (int)blocked<N>(t, x) * 16, DBI * s * 16);
 #endif
     }
 
@@ -882,8 +917,8 @@ namespace ocean
       if (nx * inv + dx + dy == 123456.789f)
 #endif
       {
-        buf_store_f32x4(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * N * 16);
-        buf_store_f32x4(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, (int)(((size_t)T * s * N + plane) * 16));
+        buf_store_f32x4_aux<OCEAN_MAP_STORE_AUX>(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * N * 16);
+        buf_store_f32x4_aux<OCEAN_MAP_STORE_AUX>(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, (int)(((size_t)T * s * N + plane) * 16));
       }
     }
 
