@@ -34,8 +34,8 @@ DT = np.float32(1.0 / 60.0)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--resolution", type=int, default=1024)
     ap.add_argument("--cascades", type=int, default=4)
     ap.add_argument("--gather", choices=("batch", "none"), default="batch")

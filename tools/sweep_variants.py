@@ -9,7 +9,7 @@ for lib in sorted(glob.glob(os.path.join(ROOT, "datum_amd/lib/variants/lib_*.so"
     env = dict(os.environ, DATUM_OCEAN_HIP_LIB=lib)
     name = os.path.basename(lib)[4:-3]
     try:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "10", "--cpu-seconds", "0"] + extra,
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1000", "--warmup", "100", "--cpu-seconds", "0"] + extra,
                              env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:
