@@ -470,3 +470,30 @@ def test_fp16_spectrum_4096(capi):
     assert rmse(got[0][..., :3], exact[0][..., :3]) < 2e-3 * scale
     assert np.abs(got[1][..., :3] - exact[1][..., :3]).max() < 2e-2
     assert np.all(got[..., 3] == 0)
+
+
+def test_gen_ragged_mesh(capi, oracle, torch):
+    # mesh sizes that are not multiples of the 16 x 16 vertex tiles (nor of a wave's 4 rows): the staged stores must
+    # neither drop nor overrun vertices (guard words after the buffer stay untouched)
+    N, sx, sy = 128, 50, 37
+    p = oracle.EXAMPLE
+    h0 = make_state(oracle, N, 1000)
+    s = oracle.example_oceanset(N, swellphase=0.3)
+    hs = capi.OceanSet.from_buffer_copy(bytes(s))
+    verts = torch.full((sx * sy * 12 + 64,), 12345.0, dtype=torch.float32, device="cuda:0")
+    with capi.Ocean(N, 1) as oc:
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        oc.upload_state(0, h0)
+        oc.update(DT)
+        oc.displace()
+        oc.gen(0, hs, sx, sy, verts.data_ptr())
+        oc.sync()
+        maps = oc.read_maps(0)
+    raw = verts.cpu().numpy()
+    assert np.all(raw[sx * sy * 12:] == 12345.0)
+    got = raw[: sx * sy * 12].reshape(sy, sx, 12)
+    want = oracle.gen(s, maps, sx, sy)
+    assert np.isfinite(got).all()
+    assert (np.abs(got[..., 0:3] - want[..., 0:3]) / (1 + np.abs(want[..., 0:3]))).max() < 2e-4
+    assert np.abs(got[..., 5:11] - want[..., 5:11]).max() < 2e-4
+    assert np.all(got[..., 11] == -1)
