@@ -112,12 +112,7 @@ namespace ocean
     return __builtin_bit_cast(cf, __builtin_amdgcn_raw_buffer_load_b64(r, voffset, soffset, 0));
   }
 
-  __device__ __forceinline__ float4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
-  {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0));
-  }
-
-  // the same with a cache-policy operand (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+  // with a cache-policy operand (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
   template<int AUX>
   __device__ __forceinline__ float4 buf_load_f32x4_aux(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
   {
@@ -128,25 +123,16 @@ namespace ocean
   // store with an SGPR offset was observed on gfx950 / ROCm 7.2 to store stale x, y components in the last lanes of
   // each 16-lane group when the next VALU instruction rewrote its data registers: hipcc enforces the "VALU write of
   // VMEM store data" wait states only when soffset is not a register (tools/dbg/colerr.py found it).
-  __device__ __forceinline__ void buf_store_f32(float v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
-  {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voffset + soffset, 0, 0);
-  }
-
   template<int AUX>
   __device__ __forceinline__ void buf_store_f32_aux(float v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
   {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voffset + soffset, 0, AUX);
   }
 
-  __device__ __forceinline__ void buf_store_cf(cf v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  template<int AUX>
+  __device__ __forceinline__ void buf_store_cf_aux(cf v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
   {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, v), r, voffset + soffset, 0, 0);
-  }
-
-  __device__ __forceinline__ void buf_store_f32x4(float4 v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
-  {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, voffset + soffset, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, v), r, voffset + soffset, 0, AUX);
   }
 
   template<int AUX>
@@ -320,17 +306,6 @@ namespace ocean
 
   // timing-only ablations (never defined in a shipped build): -DOCEAN_ABLATE_ROWLOAD / ROWSTORE / ROWFFT /
   // COLLOAD / COLSTORE / COLFFT remove one ingredient while keeping the rest alive
-#if defined(OCEAN_ABLATE_ROWSTORE) || defined(OCEAN_ABLATE_COLSTORE)
-  #define OCEAN_ABLATION 1
-#endif
-
-  // pins program order for the compiler (memory operations) and for the machine scheduler (everything):
-  // used around software prefetches so that requests are issued where they are written
-  __device__ __forceinline__ void order_fence()
-  {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  }
 
   //|---------------------- per-thread twiddles of a line transform ------------
 
@@ -723,7 +698,7 @@ namespace ocean
         // round to nearest even; the host picks specscale so that no row sum can overflow (ocean_capi: spectrum_scale)
         half4_ const hv = { (_Float16)(v[0][s].x * cc.specscale), (_Float16)(v[0][s].y * cc.specscale), (_Float16)(v[1][s].x * cc.specscale), (_Float16)(v[1][s].y * cc.specscale) };
 
-        buf_store_cf(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
+        buf_store_cf_aux<OCEAN_SPEC_STORE_AUX>(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
       }
       else
         buf_store_f32x4_aux<OCEAN_SPEC_STORE_AUX>(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
