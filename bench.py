@@ -59,6 +59,23 @@ def measured_traffic(kernel, workload):
     return None, None
 
 
+def lavapipe_probe():
+    """north_star asks for the reference's shaders on the lavapipe software-Vulkan driver as the CPU baseline.  That
+    needs a Vulkan loader, the lvp ICD, a GLSL compiler and the reference's shader sources on the box; the sources do
+    not travel (no /root/reference there) and the rest is probed here so that the JSON line says what was found."""
+    import ctypes.util
+    import glob
+    import shutil
+
+    loader = ctypes.util.find_library("vulkan")
+    icd = sorted(glob.glob("/usr/share/vulkan/icd.d/lvp_icd*.json") + glob.glob("/etc/vulkan/icd.d/lvp_icd*.json"))
+    glsl = shutil.which("glslangValidator") or shutil.which("glslc")
+    if loader and icd and glsl:
+        return f"loader {loader}, ICD {icd[0]}, {glsl} present, but the reference's shader sources are not on this box"
+    missing = [n for n, v in (("libvulkan", loader), ("lvp ICD", icd), ("glslangValidator/glslc", glsl)) if not v]
+    return "unavailable: no " + ", no ".join(missing)
+
+
 def cpu_baseline(N, cascades, states, budget):
     """The oracle (oracle/ocean_oracle.cpp, OpenMP over rows / columns) timed on this host on a bounded sample of
     the same workload.  A reported baseline, not a target.  kind = "port": the reference itself cannot be built or
@@ -80,7 +97,7 @@ def cpu_baseline(N, cascades, states, budget):
         el = time.perf_counter() - t0
         if el >= budget or grids >= 64 * cascades:
             break
-    return dict(value=grids / el, unit="grids/s", cores=oracle.num_threads(), kind="port",
+    return dict(value=grids / el, unit="grids/s", cores=oracle.num_threads(), kind="port", lavapipe=lavapipe_probe(),
                 sample=f"{grids} grids = {grids // cascades} steps of {N}x{N} x {cascades} cascades in {el:.1f} s, "
                        f"oracle/ocean_oracle.cpp with OpenMP over rows/columns")
 
