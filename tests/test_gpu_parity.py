@@ -497,3 +497,23 @@ def test_gen_ragged_mesh(capi, oracle, torch):
     assert (np.abs(got[..., 0:3] - want[..., 0:3]) / (1 + np.abs(want[..., 0:3]))).max() < 2e-4
     assert np.abs(got[..., 5:11] - want[..., 5:11]).max() < 2e-4
     assert np.all(got[..., 11] == -1)
+
+
+@pytest.mark.parametrize("N", [64, 1024])
+def test_flat_ocean(capi, N):
+    # the empty input: h0 = 0 everywhere -> zero displacement, normals exactly along z up to the reciprocal square
+    # root's rounding, nothing non-finite (1/|k| at k = 0 and the zero-length slopes are the places that could)
+    with capi.Ocean(N, 2) as oc:
+        for c in range(2):
+            oc.set_cascade(c, 22.0 * (c + 1), 1.35)
+            oc.upload_state(c, np.zeros((N, N, 2), np.float32))
+        for fp16 in (False, True):
+            oc.set_spectrum_format(fp16)
+            oc.update(DT)
+            oc.displace()
+            for c in range(2):
+                m = oc.read_maps(c)
+                assert np.isfinite(m).all()
+                assert np.all(m[0] == 0)
+                assert np.all(m[1][..., :2] == 0) and np.all(m[1][..., 3] == 0)
+                assert np.abs(m[1][..., 2] - 1).max() < 1e-6
