@@ -745,8 +745,12 @@ namespace ocean
   // One tile per workgroup.  (A persistent variant -- workgroups walking a run of tiles, the next tile's values
   // requested ahead and the map stores draining behind -- was measured 15 % slower: this pass runs at the rate the
   // memory system moves its 48 B/pt, and queueing more requests per workgroup only delays the first ones.)
+#ifndef OCEAN_COL_MINBLOCKS
+#define OCEAN_COL_MINBLOCKS 1
+#endif
+
   template<int N, bool H16>
-  __global__ void __launch_bounds__(ColCfg<N>::THREADS) ocean_colpass_kernel(StepArgs a)
+  __global__ void __launch_bounds__(ColCfg<N>::THREADS, OCEAN_COL_MINBLOCKS) ocean_colpass_kernel(StepArgs a)
   {
     typedef Plan<N> P;
     typedef LineFFT<N> L;

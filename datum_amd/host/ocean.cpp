@@ -433,6 +433,9 @@ bool prepare_ocean_context(DatumPlatform::PlatformInterface &platform, OceanCont
   if (rc != DATUM_OCEAN_OK)
     throw runtime_error(string("HIP ocean module create failed: ") + datum_ocean_last_error(nullptr));
 
+  if (context.spectrumfp16)
+    check(context.hip, datum_ocean_set_spectrum_format(context.hip, DATUM_OCEAN_SPECTRUM_FP16), "datum_ocean_set_spectrum_format");
+
   context.ready = true;
 
   return true;

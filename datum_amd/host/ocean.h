@@ -134,6 +134,8 @@ struct OceanContext
 
   int device = 0;
 
+  bool spectrumfp16 = false;              // extension: store the module's work spectrum as halves (set before prepare_ocean_context)
+
   datum_ocean_t hip = nullptr;            // replaces vulkan / pipelines / oceanset / spectrum / displacementmap
 
   void *rendercomplete = nullptr;         // hipEvent_t recorded behind the last render (ocean.h:45)
