@@ -896,8 +896,9 @@ namespace ocean
       if (nx * inv + dx + dy == 123456.789f)
 #endif
       {
-        // (32-byte runs of a 2-column tile written through one by one: 487 us against 268 us at 4096^2)
-        constexpr int MAPAUX = (W >= 4) ? OCEAN_MAP_STORE_AUX : 0;
+        // (at 4096^2, where the 537 MB of maps are far beyond the Infinity Cache, writing through costs 2x: 487-525 us
+        // against 250-260 us, with 32-byte runs of 2-column tiles and with 64-byte runs of two columns per thread alike)
+        constexpr int MAPAUX = (N <= 2048) ? OCEAN_MAP_STORE_AUX : 0;
 
         buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * N * 16);
         buf_store_f32x4_aux<MAPAUX>(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, (int)(((size_t)T * s * N + plane) * 16));

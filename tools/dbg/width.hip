@@ -61,6 +61,24 @@ __global__ void __launch_bounds__(256) rowlike(float2 const* __restrict__ h0, fl
       *reinterpret_cast<float4*>(spec + o + 2*k) = v0; *reinterpret_cast<float4*>(spec + plane + o + 2*k) = v1; *reinterpret_cast<float4*>(spec + 2*plane + o + 2*k) = v2; }
   }
 }
+// map-store pattern of the column pass: a wave stores float4 to RUN consecutive texels of each of 64*4/RUN... rows (row pitch N*16 B),
+// 2 layers; AUX = cache policy of the stores (17 = sc0 sc1)
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+template<int RUN, int AUX>
+__global__ void __launch_bounds__(512) mapstore(float4* __restrict__ maps, float v) {
+  // tile of RUN columns; 512 threads: cp = tid % RUN, t = tid / RUN; rows y = t + (512/RUN) * s, s < E2 so that the tile covers 1024 rows
+  constexpr int TT = 512 / RUN, E2 = 1024 / TT;
+  int c = blockIdx.y, tile = blockIdx.x; int cp = threadIdx.x % RUN, t = threadIdx.x / RUN; int x = tile * RUN + cp;
+  size_t plane = (size_t)N * N; float4* l0 = maps + (size_t)c * 2 * plane;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(l0, 0, (int)(2 * plane * 16), 0x00020000);
+  u4 d = { __float_as_uint(v), __float_as_uint(v + 1), __float_as_uint(v + 2), 0u };
+  #pragma unroll
+  for (int s = 0; s < E2; ++s) {
+    int y = t + TT * s; int o = (y * N + x) * 16;
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, o + (int)(plane * 16), 0, AUX);
+  }
+}
 int main() {
   size_t plane = (size_t)N*N; float2 *h0, *spec; float *phase; float *buf;
   size_t nb = (size_t)168 << 20;
@@ -76,6 +94,15 @@ int main() {
     timeit("  write 4 B/lane", nb, [&]{ hipLaunchKernelGGL(wr<float>,  dim3(g), dim3(256), 0, 0, (float*)buf,  nb/4, 1.0f); });
     timeit("  write 8 B/lane", nb, [&]{ hipLaunchKernelGGL(wr<float2>, dim3(g), dim3(256), 0, 0, (float2*)buf, nb/8, 1.0f); });
     timeit("  write 16 B/lane", nb, [&]{ hipLaunchKernelGGL(wr<float4>, dim3(g), dim3(256), 0, 0, (float4*)buf, nb/16, 1.0f); });
+  }
+  { float4* maps; CK(hipMalloc(&maps, C*2*plane*16)); double mb = 32.0*C*plane;
+    timeit("map stores, 64-B runs (4-column tiles), plain", mb, [&]{ hipLaunchKernelGGL((mapstore<4, 0>), dim3(N/4, C), dim3(512), 0, 0, maps, 1.0f); });
+    timeit("map stores, 64-B runs, sc0 sc1", mb, [&]{ hipLaunchKernelGGL((mapstore<4, 17>), dim3(N/4, C), dim3(512), 0, 0, maps, 1.0f); });
+    timeit("map stores, 128-B runs (8-column tiles), plain", mb, [&]{ hipLaunchKernelGGL((mapstore<8, 0>), dim3(N/8, C), dim3(512), 0, 0, maps, 1.0f); });
+    timeit("map stores, 128-B runs, sc0 sc1", mb, [&]{ hipLaunchKernelGGL((mapstore<8, 17>), dim3(N/8, C), dim3(512), 0, 0, maps, 1.0f); });
+    timeit("map stores, 256-B runs (16-column tiles), sc0 sc1", mb, [&]{ hipLaunchKernelGGL((mapstore<16, 17>), dim3(N/16, C), dim3(512), 0, 0, maps, 1.0f); });
+    timeit("map stores, 32-B runs (2-column tiles), plain", mb, [&]{ hipLaunchKernelGGL((mapstore<2, 0>), dim3(N/2, C), dim3(512), 0, 0, maps, 1.0f); });
+    timeit("map stores, 32-B runs, sc0 sc1", mb, [&]{ hipLaunchKernelGGL((mapstore<2, 17>), dim3(N/2, C), dim3(512), 0, 0, maps, 1.0f); });
   }
   double rowb = 40.0*C*plane;
   timeit("rowlike strided 4/8-byte accesses", rowb, [&]{ hipLaunchKernelGGL(rowlike<0>, dim3(N/2, C), dim3(256), 0, 0, h0, phase, spec); });
