@@ -13,7 +13,14 @@
 using namespace ocean;
 #define CK(x) do { hipError_t e=(x); if(e!=hipSuccess){printf("%s: %s\n",#x,hipGetErrorString(e)); return 1;} } while(0)
 int main() {
-  constexpr int N = 1024, C = 4; size_t P = (size_t)N*N;
+  
+#ifndef STAMP_N
+#define STAMP_N 1024
+#endif
+#ifndef STAMP_C
+#define STAMP_C 4
+#endif
+  constexpr int N = STAMP_N, C = STAMP_C; size_t P = (size_t)N*N;
   StepArgs a{};
   float2 *h0; float *phase; cd *spec; cf *tw; float4 *maps; float *omega; unsigned long long *stamps;
   CK(hipMalloc(&h0, C*P*8)); CK(hipMalloc(&phase, C*P*4)); CK(hipMalloc(&spec, C*P*16)); CK(hipMalloc(&maps, C*2*P*16));
@@ -29,8 +36,8 @@ int main() {
   CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS));
   CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS));
   for (int it = 0; it < 5; ++it) {
-    hipLaunchKernelGGL(ocean_rowpass_kernel<N, false>, dim3(RowCfg<N>::GROUPS, C), dim3(RowCfg<N>::THREADS), RowCfg<N>::LDS, 0, a);
-    hipLaunchKernelGGL(ocean_colpass_kernel<N, false>, dim3(ColCfg<N>::TILES, C), dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, 0, a);
+    hipLaunchKernelGGL((ocean_rowpass_kernel<N, false>), dim3(RowCfg<N>::GROUPS, C), dim3(RowCfg<N>::THREADS), RowCfg<N>::LDS, 0, a);
+    hipLaunchKernelGGL((ocean_colpass_kernel<N, false>), dim3(ColCfg<N>::TILES, C), dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, 0, a);
   }
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> st(nst); CK(hipMemcpy(st.data(), stamps, nst*8, hipMemcpyDeviceToHost));
