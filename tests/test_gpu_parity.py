@@ -517,3 +517,38 @@ def test_flat_ocean(capi, N):
                 assert np.all(m[0] == 0)
                 assert np.all(m[1][..., :2] == 0) and np.all(m[1][..., 3] == 0)
                 assert np.abs(m[1][..., 2] - 1).max() < 1e-6
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_parameters(capi, oracle, case):
+    # three cascades with random wave scales (1 .. 2000), choppiness (0 .. 2), and random runs of 1 .. 12 updates between
+    # displacements (more than 8 pending goes through the phase-only kernel first), some dt negative or large (the
+    # general fmod path): phase bit-exact, maps within 2e-6 of the largest |value| of the oracle's (the 1e-5 absolute
+    # bar belongs to the example parameters; amplitudes here span decades)
+    rng = np.random.default_rng(100 + case)
+    N = [128, 256, 64, 512, 128, 256][case]
+    C = 3
+    scales = np.exp(rng.uniform(0.0, np.log(2000.0), C)).astype(np.float32)
+    chops = rng.uniform(0.0, 2.0, C).astype(np.float32)
+    states = [make_state(oracle, N, 2000 + 10 * case + c, wavescale=float(scales[c])) for c in range(C)]
+    phases = [np.zeros((N, N), np.float32) for _ in range(C)]
+    w = oracle.weights(N, reduced=True)
+    with capi.Ocean(N, C) as oc:
+        for c in range(C):
+            oc.set_cascade(c, float(scales[c]), float(chops[c]))
+            oc.upload_state(c, states[c])
+        for rnd in range(3):
+            for _ in range(int(rng.integers(1, 13))):
+                dt = np.float32(rng.choice([1 / 60, 1 / 30, 0.25, -1 / 60, 7.5, 0.0]))
+                oc.update(float(dt))
+                for c in range(C):
+                    oracle.update(phases[c], float(scales[c]), dt)
+            oc.displace()
+            for c in range(C):
+                assert np.array_equal(oc.read_state(c), phases[c])
+                ref = oracle.displace(states[c], phases[c].copy(), float(scales[c]), float(chops[c]), w=w)
+                got = oc.read_maps(c)
+                tol = 2e-6 * max(float(np.abs(ref[0]).max()), 1e-12)
+                assert np.abs(got[0][..., :3] - ref[0][..., :3]).max() < 10 * tol
+                assert rmse(got[0][..., :3], ref[0][..., :3]) < tol
+                assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 2e-5
