@@ -79,6 +79,22 @@ __global__ void __launch_bounds__(512) mapstore(float4* __restrict__ maps, float
     __builtin_amdgcn_raw_buffer_store_b128(d, r, o + (int)(plane * 16), 0, AUX);
   }
 }
+// the same map-store pattern writing only x, y, z of every texel (12 of 16 bytes: the w components stay as they are)
+typedef unsigned int u3 __attribute__((ext_vector_type(3)));
+template<int RUN, int AUX>
+__global__ void __launch_bounds__(512) mapstore12(float4* __restrict__ maps, float v) {
+  constexpr int TT = 512 / RUN, E2 = 1024 / TT;
+  int c = blockIdx.y, tile = blockIdx.x; int cp = threadIdx.x % RUN, t = threadIdx.x / RUN; int x = tile * RUN + cp;
+  size_t plane = (size_t)N * N; float4* l0 = maps + (size_t)c * 2 * plane;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(l0, 0, (int)(2 * plane * 16), 0x00020000);
+  u3 d = { __float_as_uint(v), __float_as_uint(v + 1), __float_as_uint(v + 2) };
+  #pragma unroll
+  for (int s = 0; s < E2; ++s) {
+    int y = t + TT * s; int o = (y * N + x) * 16;
+    __builtin_amdgcn_raw_buffer_store_b96(d, r, o, 0, AUX);
+    __builtin_amdgcn_raw_buffer_store_b96(d, r, o + (int)(plane * 16), 0, AUX);
+  }
+}
 int main() {
   size_t plane = (size_t)N*N; float2 *h0, *spec; float *phase; float *buf;
   size_t nb = (size_t)168 << 20;
@@ -98,6 +114,8 @@ int main() {
   { float4* maps; CK(hipMalloc(&maps, C*2*plane*16)); double mb = 32.0*C*plane;
     timeit("map stores, 64-B runs (4-column tiles), plain", mb, [&]{ hipLaunchKernelGGL((mapstore<4, 0>), dim3(N/4, C), dim3(512), 0, 0, maps, 1.0f); });
     timeit("map stores, 64-B runs, sc0 sc1", mb, [&]{ hipLaunchKernelGGL((mapstore<4, 17>), dim3(N/4, C), dim3(512), 0, 0, maps, 1.0f); });
+    timeit("map stores, 12 of 16 B per texel, 64-B runs, plain", mb, [&]{ hipLaunchKernelGGL((mapstore12<4, 0>), dim3(N/4, C), dim3(512), 0, 0, maps, 1.0f); });
+    timeit("map stores, 12 of 16 B per texel, 64-B runs, sc0 sc1", mb, [&]{ hipLaunchKernelGGL((mapstore12<4, 17>), dim3(N/4, C), dim3(512), 0, 0, maps, 1.0f); });
     timeit("map stores, 128-B runs (8-column tiles), plain", mb, [&]{ hipLaunchKernelGGL((mapstore<8, 0>), dim3(N/8, C), dim3(512), 0, 0, maps, 1.0f); });
     timeit("map stores, 128-B runs, sc0 sc1", mb, [&]{ hipLaunchKernelGGL((mapstore<8, 17>), dim3(N/8, C), dim3(512), 0, 0, maps, 1.0f); });
     timeit("map stores, 256-B runs (16-column tiles), sc0 sc1", mb, [&]{ hipLaunchKernelGGL((mapstore<16, 17>), dim3(N/16, C), dim3(512), 0, 0, maps, 1.0f); });
