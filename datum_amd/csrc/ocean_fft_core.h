@@ -110,7 +110,18 @@ namespace ocean
 
   //|---------------------- plan ----------------------------------------------
 
-  constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
+  // (a loop, not a recursion: where the exponent is an unrolled loop counter rather than a constant expression the call
+  // must inline and fold; hipcc emitted a real device-function call plus runtime divisions for the recursive form in
+  // one translation unit -- 155 instead of 100 VGPRs in the row pass -- and folded it in another)
+  OC_HD constexpr int ipow(int b, int e)
+  {
+    int r = 1;
+
+    for(int i = 0; i < e; ++i)
+      r *= b;
+
+    return r;
+  }
 
   // N = E^(NP-1) * RL: NP-1 passes of radix E, one last pass of radix RL <= E done as M = E/RL tasks.
   // E = 8 keeps a line transform near 50 VGPRs (E = 16: ~90) so that several lines per thread fit in registers.
