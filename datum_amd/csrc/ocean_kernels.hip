@@ -248,21 +248,9 @@ namespace ocean
     *cos_out = ((q + 1) & 2) ? -c : c;
   }
 
-  // one point of data/ocean.sim.comp:52-66: h~ from h0(k), h0 at the mirror index and the phase
-  __device__ __forceinline__ cf sim_height(float2 h0k, float2 h0mk, float phase)
-  {
-    float sin_v, cos_v;
-    sincos_phase(phase, &sin_v, &cos_v);
-
-    cf h;
-    h.x = (h0k.x + h0mk.x) * cos_v - (h0k.y + h0mk.y) * sin_v;
-    h.y = (h0k.x - h0mk.x) * sin_v + (h0k.y - h0mk.y) * cos_v;
-
-    return h;
-  }
-
-  // the same value as  h0(k) e^{i phase} + conj(h0(mirror) e^{i phase})  (two complex products and a conjugating
-  // add: 5 packed instructions; equal to the expanded form above up to rounding)
+  // one point of data/ocean.sim.comp:52-66: h~ from h0(k), h0 at the mirror index and the phase, evaluated as
+  // h0(k) e^{i phase} + conj(h0(mirror) e^{i phase})  (two complex products and a conjugating add: 5 packed
+  // instructions; equal to the shader's expanded form, sim.comp:65-66, up to rounding)
   __device__ __forceinline__ cf sim_height_products(float2 h0k, float2 h0mk, float phase)
   {
     float sin_v, cos_v;
@@ -1025,7 +1013,8 @@ namespace ocean
 
   //|---------------------- diagnostics ---------------------------------------
 
-  // ocean.sim alone, row-major output (datum_ocean_debug_sim)
+  // ocean.sim alone, row-major output (datum_ocean_debug_sim): h~ by the same function the row pass uses
+  // (sim_height_products), so that the stage test pins the product's arithmetic, not a sibling of it
   __global__ void ocean_sim_kernel(StepArgs a, int N, int cascade, cf *h, cf *hx, cf *hy)
   {
     size_t const plane = (size_t)N * N;
@@ -1038,7 +1027,7 @@ namespace ocean
     {
       int y = (int)(i / N), x = (int)(i % N);
 
-      cf hh = sim_height(h0[i], h0[(size_t)(N - 1 - y) * N + (N - 1 - x)], phase[i]);
+      cf hh = sim_height_products(h0[i], h0[(size_t)(N - 1 - y) * N + (N - 1 - x)], phase[i]);
       float2 kn = knorm_of(wavevector(x, N, scale), wavevector(y, N, scale));
 
       h[i] = hh;

@@ -38,3 +38,32 @@ def oracle():
 
     o.build()
     return o
+
+
+_REPORT = []
+
+
+@pytest.fixture(scope="session")
+def report():
+    """Measured parity figures (RMSE per size, against the literal- and the reduced-table oracle ...) collected by the
+    GPU tests and written to gpurun_out/parity_table.txt at the end of the session; the copy under profiles/ is what
+    DESIGN.md quotes."""
+
+    def add(line):
+        _REPORT.append(line)
+
+    return add
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _REPORT:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_table.txt"), "w") as f:
+            f.write("# measured by pytest tests -m gpu (tests/conftest.py: report fixture); one line per check\n")
+            for line in _REPORT:
+                f.write(line + "\n")
+    except OSError:
+        pass
