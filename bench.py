@@ -214,7 +214,7 @@ def main():
 
     if rank == 0:
         # sanity: the maps of the last step are finite and non-trivial
-        chk = maps[: 2 * N * N * 4].view(2, N, N, 4)
+        chk = capi.map_layers(maps[: 2 * N * N * 4], N)
         if not args.no_check:
             assert bool(torch.isfinite(chk).all()) and float(chk[0, ..., 2].abs().max()) > 0
 

@@ -53,6 +53,7 @@ SYMBOLS = {
     "datum_ocean_set_stream": (I, [P, P, I]),
     "datum_ocean_bind_maps": (I, [P, P, ctypes.c_size_t]),
     "datum_ocean_maps_device": (I, [P, ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]),
+    "datum_ocean_map_group": (I, []),
     "datum_ocean_set_cascade": (I, [P, I, F, F]),
     "datum_ocean_set_spectrum_format": (I, [P, I]),
     "datum_ocean_upload_state": (I, [P, I, P, P]),
@@ -243,6 +244,17 @@ class Ocean:
         row, col = D(), D()
         self._check(self.lib.datum_ocean_algorithmic_bytes(self.h, ctypes.byref(row), ctypes.byref(col)))
         return row.value, col.value
+
+
+def map_layers(raw, N):
+    """View of one cascade's DEVICE map block (2*N*N*4 floats as the kernels lay them out: per row, groups of G texels,
+    layer 0 of the group then layer 1 of the group -- include/datum_ocean_hip.h) as the reference's logical image
+    [layer][y][x][4].  Works on numpy arrays and torch tensors alike (reshape / permute only)."""
+    G = load().datum_ocean_map_group()
+    v = raw.reshape(N, N // G, 2, G, 4)          # [y][group][layer][x % G][component]
+    if hasattr(v, "permute"):
+        return v.permute(2, 0, 1, 3, 4).reshape(2, N, N, 4)
+    return v.transpose(2, 0, 1, 3, 4).reshape(2, N, N, 4)
 
 
 def reference_weights(N):

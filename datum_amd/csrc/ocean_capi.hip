@@ -15,6 +15,7 @@
 #include <hip/hip_ext.h>
 
 #include "ocean_kernels.hip"
+#include "ocean_gen.hip"
 
 using namespace ocean;
 
@@ -129,7 +130,10 @@ namespace
 
     hipError_t e = configure_one<N, false>(what);
 
-    return (e != hipSuccess) ? e : configure_one<N, true>(what);
+    if (e == hipSuccess)
+      e = configure_one<N, true>(what);
+
+    return e;
   }
 
   // ev != nullptr: the dispatch itself carries a start and a stop event (hipExtLaunchKernel), so a sampled kernel is
@@ -395,8 +399,6 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
     DISPATCH_N(resolution, ce = configure<NN>(ctx, &what));
     if (ce != hipSuccess)
     {
-      char buf[256];
-      snprintf(buf, sizeof(buf), "%s [row %zu B, col %zu B]", what, (size_t)0, (size_t)0);
       int rc = fail(nullptr, (int)ce, what);
       datum_ocean_destroy(ctx);
       return rc;
@@ -492,6 +494,11 @@ int datum_ocean_maps_device(datum_ocean_t ctx, void **device_ptr, size_t *bytes)
     *bytes = ctx->cascades * 2 * plane(ctx) * sizeof(float4);
 
   return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_map_group(void)
+{
+  return MAP_GROUP;
 }
 
 int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, float choppiness)
@@ -774,17 +781,17 @@ int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, 
   GenArgs g;
   g.set = *set;
   g.frame = make_gen_frame(*set);
-  g.layer0 = ctx->maps + (size_t)cascade * 2 * plane(ctx);
-  g.layer1 = g.layer0 + plane(ctx);
+  g.map = ctx->maps + (size_t)cascade * 2 * plane(ctx);
   g.N = ctx->N;
   g.sizex = sizex;
   g.sizey = sizey;
+  g.tilesx = (sizex + GEN_TILE - 1) / GEN_TILE;
+  g.tiles = g.tilesx * ((sizey + GEN_TILE - 1) / GEN_TILE);
   g.vertices = (float*)vertices_device;
 
-  dim3 grid((sizex + 15) / 16, (sizey + 15) / 16);
+  void *args[] = { &g };
 
-  hipLaunchKernelGGL(ocean_gen_kernel, grid, dim3(256), 0, ctx->stream, g);
-  HIPCHECK(ctx, hipGetLastError());
+  HIPCHECK(ctx, hipLaunchKernel(reinterpret_cast<void const*>(&ocean_gen_kernel), dim3(g.tiles), dim3(GEN_THREADS), args, GEN_LDS, ctx->stream));
 
   return DATUM_OCEAN_OK;
 }
@@ -801,8 +808,21 @@ int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps)
 
   size_t const P = plane(ctx);
 
-  HIPCHECK(ctx, hipMemcpyAsync(maps, ctx->maps + (size_t)cascade * 2 * P, 2 * P * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  // the device layout interleaves the layers in groups of four texels (ocean_kernels.hip: map_index); hand out the
+  // reference's logical image, [layer][y][x]
+  std::vector<float4> raw;
+  try { raw.resize(2 * P); } catch (...) { return fail(ctx, DATUM_OCEAN_ENOMEM, "datum_ocean_read_maps: out of host memory"); }
+
+  HIPCHECK(ctx, hipMemcpyAsync(raw.data(), ctx->maps + (size_t)cascade * 2 * P, 2 * P * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  int const N = ctx->N;
+  float4 *out = reinterpret_cast<float4*>(maps);
+
+  for(int layer = 0; layer < 2; ++layer)
+    for(int y = 0; y < N; ++y)
+      for(int x = 0; x < N; ++x)
+        out[(size_t)layer * P + (size_t)y * N + x] = raw[map_index(N, y, x, layer)];
 
   return DATUM_OCEAN_OK;
 }

@@ -21,6 +21,8 @@
 // Built with -ffp-contract=off: products and sums are rounded as written (the phase state is
 // bit-identical to the host formula); the FFT butterflies ask for their FMAs explicitly.
 
+#pragma once
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -55,7 +57,7 @@ namespace ocean
     float2 const *h0;    // [cascade][N*N]       OceanSet::h0
     float *phase;        // [cascade][N*N]       OceanSet::phase
     void *spec;          // [cascade][N*N]       work spectrum (replaces Spectrum::h, hx, hy), blocked layout: cd, or ch (fp16 variant)
-    float4 *maps;        // [cascade][2][N*N]    displacementmap, 2 layers RGBA32F
+    float4 *maps;        // [cascade][2*N*N]     displacementmap, 2 layers RGBA32F, texel groups interleaved (map_index)
     cf const *tw;        // [N]                  exp(+2 pi i k / N)
     float const *omega;  // [cascade][(N/2+1)^2] dispersion(k) by (|m - N/2|, |n - N/2|)
     int ndt;
@@ -82,6 +84,24 @@ namespace ocean
   __host__ __device__ __forceinline__ constexpr size_t blocked(int y, int x)
   {
     return ((size_t)((y >> 3) * (N / 8) + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7);
+  }
+
+  // Displacement map layout (private to this module: in the reference the map is a VK_IMAGE_TILING_OPTIMAL 2-layer
+  // image whose only reader is ocean.gen's sampler, ocean.cpp:706, gen.comp:113-114).  Per cascade, per row y, groups of
+  // G = OCEAN_MAP_GROUP texels: 16 G bytes of layer 0 (displacement) of texels G g .. G g + G - 1, then 16 G bytes of
+  // layer 1 (normal) of the same texels, so that a bilinear corner of ocean.gen finds its displacement and its normal in
+  // one cache line instead of two lines 16 N^2 bytes apart.  G = 4: one 128-byte line holds both layers of four
+  // neighbouring texels and a store instruction of a four-column tile writes a 64-byte run.  G = 1: the two layers of a
+  // texel are adjacent (32 bytes).
+#ifndef OCEAN_MAP_GROUP
+#define OCEAN_MAP_GROUP 4
+#endif
+  constexpr int MAP_GROUP = OCEAN_MAP_GROUP;
+
+  // float4 index of texel (x, y) of `layer`:
+  __host__ __device__ __forceinline__ constexpr size_t map_index(int N, int y, int x, int layer)
+  {
+    return (size_t)y * 2 * N + (size_t)(x / MAP_GROUP) * (2 * MAP_GROUP) + layer * MAP_GROUP + (x % MAP_GROUP);
   }
 
   //|---------------------- buffer addressing ----------------------------------
@@ -864,7 +884,12 @@ namespace ocean
 
     float const nz = cc.nz;
 
-    int const o0 = (t * N + x) * 16;                 // byte offset of this thread's first texel
+    int const o0 = (int)map_index(N, t, x, 0) * 16;   // byte offset of this thread's first texel (layer 0; layer 1 is 16 MAP_GROUP bytes on)
+
+    // line stores (four-column tiles): this lane's 16 bytes of row (t & ~1) and of row (t | 1): the even quad writes
+    // the displacement half of either line, the odd quad the normal half
+    int const olo = (int)map_index(N, t & ~1, x, t & 1) * 16;
+    int const ohi = (int)map_index(N, t | 1, x, t & 1) * 16;
 
     #pragma unroll
     for(int s = 0; s < E; ++s)
@@ -888,8 +913,35 @@ namespace ocean
         // against 250-260 us, with 32-byte runs of 2-column tiles and with 64-byte runs of two columns per thread alike)
         constexpr int MAPAUX = (N <= 2048) ? OCEAN_MAP_STORE_AUX : 0;
 
-        buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * N * 16);
-        buf_store_f32x4_aux<MAPAUX>(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, (int)(((size_t)T * s * N + plane) * 16));
+#ifndef OCEAN_COL_LINE_STORES
+#define OCEAN_COL_LINE_STORES 1
+#endif
+        if constexpr (OCEAN_COL_LINE_STORES && W == 4 && MAP_GROUP == 4)
+        {
+          // Lanes 4 k .. 4 k + 3 of a wave hold the four texels of row t, the next four lanes those of row t + 1.  The
+          // two rows trade halves (DPP row shifts by four lanes), so that ONE store instruction writes a row's whole
+          // 128-byte line -- 64 bytes of displacement from the even quad, 64 bytes of normal from the odd quad -- instead of
+          // two instructions writing one half each (written through, half lines cost 24 us per 134 MB against 19-20 us).
+          float const dsp[3] = { dx, dy, dz }, nrm[3] = { nx * inv, ny * inv, nz * inv };
+          float lo[3], hi[3];
+
+          #pragma unroll
+          for(int k = 0; k < 3; ++k)
+          {
+            // row of the even quad: its own displacement | the normal of the even quad, fetched by the odd quad from four lanes down
+            lo[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, dsp[k]), __builtin_bit_cast(int, nrm[k]), 0x114, 0xF, 0xA, false));
+            // row of the odd quad: the displacement of the odd quad, fetched by the even quad from four lanes up | its own normal
+            hi[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, nrm[k]), __builtin_bit_cast(int, dsp[k]), 0x104, 0xF, 0x5, false));
+          }
+
+          buf_store_f32x4_aux<MAPAUX>(make_float4(lo[0], lo[1], lo[2], 0.0f), rmaps, olo, T * s * 2 * N * 16);
+          buf_store_f32x4_aux<MAPAUX>(make_float4(hi[0], hi[1], hi[2], 0.0f), rmaps, ohi, T * s * 2 * N * 16);
+        }
+        else
+        {
+          buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * 2 * N * 16);
+          buf_store_f32x4_aux<MAPAUX>(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, T * s * 2 * N * 16 + MAP_GROUP * 16);
+        }
       }
     }
 
@@ -1036,212 +1088,4 @@ namespace ocean
     }
   }
 
-  //|---------------------- ocean.gen -----------------------------------------
-
-  // per-launch constants of ocean.gen that do not depend on the vertex (gen.comp:75-79,93-99), evaluated once on the
-  // host in the shader's operation order instead of once per thread (gfx950 has no scalar float unit)
-  struct GenFrame
-  {
-    float camerapos[3];
-    float cameraheight;
-    float margin;
-    float frequency;
-    float qi;
-    float phi;
-  };
-
-  struct GenArgs
-  {
-    datum_ocean_set set;
-    GenFrame frame;
-    float4 const *layer0;
-    float4 const *layer1;
-    int N;
-    int sizex;
-    int sizey;
-    float *vertices;
-  };
-
-  struct f3 { float x, y, z; };
-
-  __host__ __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
-  __host__ __device__ __forceinline__ f3 operator*(float s, f3 a) { return { s * a.x, s * a.y, s * a.z }; }
-  __host__ __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-  __host__ __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
-
-  // a / |a|: IEEE square root and divisions, as the oracle does it -- for the view ray, whose direction decides where a
-  // grazing ray meets the plane (one ulp there moves horizon vertices by whole texels)
-  __device__ __forceinline__ f3 normalize3_exact(f3 a) { float l = sqrtf(dot3(a, a)); return { a.x / l, a.y / l, a.z / l }; }
-
-  // a / |a| with the hardware reciprocal square root (1 ulp): the shading frame, where errors are not amplified
-  __device__ __forceinline__ f3 normalize3(f3 a) { float inv = __builtin_amdgcn_rsqf(dot3(a, a)); return { a.x * inv, a.y * inv, a.z * inv }; }
-
-  // rotate v by the unit quaternion q = (w, x, y, z)   (data/transform.inc:32-37)
-  __device__ __forceinline__ f3 rotate(float const (&q)[4], f3 v)
-  {
-    f3 u = { q[1], q[2], q[3] };
-    f3 tt = 2.0f * cross3(u, v);
-
-    return v + q[0] * tt + cross3(u, tt);
-  }
-
-  inline GenFrame make_gen_frame(datum_ocean_set const &p)
-  {
-    GenFrame f;
-
-    // camerapos = 2 * (dual * conjugate(real)).yzw   (gen.comp:75, transform.inc:13-28)
-    float rw = p.camera_real[0], ri = -p.camera_real[1], rj = -p.camera_real[2], rk = -p.camera_real[3];
-    float dw = p.camera_dual[0], di = p.camera_dual[1], dj = p.camera_dual[2], dk = p.camera_dual[3];
-
-    f.camerapos[0] = 2 * (dw * ri + di * rw + dj * rk - dk * rj);
-    f.camerapos[1] = 2 * (dw * rj + dj * rw + dk * ri - di * rk);
-    f.camerapos[2] = 2 * (dw * rk + dk * rw + di * rj - dj * ri);
-
-    f.cameraheight = (p.plane[0] * f.camerapos[0] + p.plane[1] * f.camerapos[1] + p.plane[2] * f.camerapos[2]) + p.plane[3];
-    f.margin = 1 + sqrtf((2 * p.swellamplitude + 0.5f) / f.cameraheight);
-
-    // Gerstner swell constants (gen.comp:93-99)
-    f.frequency = 2 * 3.14159265358979323846f / p.swelllength;
-    f.qi = p.swellsteepness / (f.frequency * p.swellamplitude * 4 + 1e-6f);
-    f.phi = f.frequency * p.swellamplitude;
-
-
-    return f;
-  }
-
-  // texture(sampler2DArray, REPEAT, linear, lod 0) of both layers at normalised (u, v): texel centres at (i + 0.5) / N.
-  // N is a power of two: REPEAT is a mask (two's complement makes it right for negative texel indices too).
-  __device__ __forceinline__ void sample_repeat2(float4 const *layer0, float4 const *layer1, int N, float u, float v, f3 &s0, f3 &s1)
-  {
-    float fx = u * (float)N - 0.5f;
-    float fy = v * (float)N - 0.5f;
-
-    float flx = floorf(fx);
-    float fly = floorf(fy);
-
-    float ax = fx - flx;
-    float ay = fy - fly;
-
-    int i0 = (int)flx & (N - 1);
-    int j0 = (int)fly & (N - 1);
-    int i1 = (i0 + 1) & (N - 1);
-    int j1 = (j0 + 1) & (N - 1);
-
-    int const o00 = j0 * N + i0, o10 = j0 * N + i1, o01 = j1 * N + i0, o11 = j1 * N + i1;
-
-    float4 a00 = layer0[o00], a10 = layer0[o10], a01 = layer0[o01], a11 = layer0[o11];
-    float4 b00 = layer1[o00], b10 = layer1[o10], b01 = layer1[o01], b11 = layer1[o11];
-
-    float w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
-
-    s0 = { w00 * a00.x + w10 * a10.x + w01 * a01.x + w11 * a11.x,
-           w00 * a00.y + w10 * a10.y + w01 * a01.y + w11 * a11.y,
-           w00 * a00.z + w10 * a10.z + w01 * a01.z + w11 * a11.z };
-
-    s1 = { w00 * b00.x + w10 * b10.x + w01 * b01.x + w11 * b11.x,
-           w00 * b00.y + w10 * b10.y + w01 * b01.y + w11 * b11.y,
-           w00 * b00.z + w10 * b10.z + w01 * b01.z + w11 * b11.z };
-  }
-
-  // data/ocean.gen.comp:67-137, one thread per mesh vertex, 16 x 16 vertices per workgroup (the bilinear fetches of
-  // neighbours share cache lines in both directions).  The 48-byte vertices go through LDS so that each store
-  // instruction of a wave writes whole 16-byte-per-lane runs of its four 768-byte row segments (three 16-byte stores
-  // per thread at a 48-byte stride touched every line three times: 26 -> 21 us per 1024^2 mesh from 64^2 maps).
-  __global__ void __launch_bounds__(256) ocean_gen_kernel(GenArgs g)
-  {
-    __shared__ float4 stage[3 * 256];
-
-    int const xx = blockIdx.x * 16 + (threadIdx.x & 15);
-    int const yy = blockIdx.y * 16 + (threadIdx.x >> 4);
-
-    datum_ocean_set const &p = g.set;
-    GenFrame const &f = g.frame;
-
-    f3 const camerapos = { f.camerapos[0], f.camerapos[1], f.camerapos[2] };
-    f3 const planen = { p.plane[0], p.plane[1], p.plane[2] };
-
-    // exactly the shader's expressions up to the base position: near the horizon the plane hit is ill-conditioned
-    float u = (2 * (float)xx / (float)(g.sizex - 1) - 1) * f.margin;
-    float v = (1 - 2 * (float)yy / (float)(g.sizey - 1)) * f.margin;
-
-    float const *ip = p.invproj;
-
-    f3 viewvec = { ip[0] * u + ip[1] * v + ip[2] * 0.0f + ip[3] * 1.0f,
-                   ip[4] * u + ip[5] * v + ip[6] * 0.0f + ip[7] * 1.0f,
-                   ip[8] * u + ip[9] * v + ip[10] * 0.0f + ip[11] * 1.0f };
-
-    f3 worlddir = rotate(p.camera_real, normalize3_exact(viewvec));
-
-    float costheta = dot3(worlddir, f3{ -planen.x, -planen.y, -planen.z });
-
-    float dist = (costheta > 0) ? f.cameraheight / costheta : 1e6f;
-
-    f3 baseposition = { camerapos.x + dist * worlddir.x, camerapos.y + dist * worlddir.y, -p.plane[3] };
-
-    // Gerstner swell (gen.comp:93-109)
-    float const amplitude = p.swellamplitude;
-    float const dirx = p.swelldirection[0], diry = p.swelldirection[1];
-    float const qi = f.qi, phi = f.phi;
-
-    float theta = f.frequency * (dirx * baseposition.x + diry * baseposition.y) + p.swellphase;
-
-    float st, ct;
-    sincosf(theta, &st, &ct);        // theta reaches 1e5 at the horizon: full-range reduction
-
-    f3 position = { baseposition.x + qi * amplitude * dirx * ct, baseposition.y + qi * amplitude * diry * ct, baseposition.z + amplitude * st };
-
-    float const sixth = 1.0f / 6;
-
-    f3 normal = { phi * dirx * ct * sixth, phi * diry * ct * sixth, qi * phi * st };
-    f3 tangent = { qi * phi * dirx * dirx * st, qi * phi * diry * dirx * st, phi * dirx * ct * sixth };
-
-    f3 tbn2 = normalize3(f3{ -normal.x, -normal.y, 1 - normal.z });
-    f3 tbn0 = normalize3(f3{ 1 - tangent.x, -tangent.y, tangent.z });
-    f3 tbn1 = cross3(tbn0, tbn2);
-
-    float tu = position.x * p.scale;
-    float tv = position.y * p.scale;
-
-    f3 displacement, dn;
-    sample_repeat2(g.layer0, g.layer1, g.N, tu, tv, displacement, dn);
-
-    float cl = dist * p.smoothing - 0.35f;
-    cl = fminf(fmaxf(cl, 0.0f), 1.0f);
-    float smoothing = __builtin_amdgcn_exp2f(0.2f * __builtin_amdgcn_logf(cl));   // pow(cl, 0.2): 0 -> 0, 1 -> 1
-
-    f3 tn = dn.x * tbn0 + dn.y * tbn1 + dn.z * tbn2;
-
-    tbn2 = normalize3((1 - smoothing) * tn + smoothing * planen);
-
-    float d0 = tbn2.x;
-    tbn0 = normalize3(f3{ 1 - d0 * tbn2.x, 0 - d0 * tbn2.y, 0 - d0 * tbn2.z });
-
-    // Mesh::Vertex { position3, texcoord2, normal3, tangent4 } = 48 bytes = three float4 per vertex, through LDS:
-    // thread i of a wave then stores float4 number i, 64 + i, 128 + i of the wave's 192
-    int const lane = threadIdx.x & 63;
-    float4 *mine = stage + 3 * (threadIdx.x - lane);       // this wave's 192 float4
-
-    mine[3 * lane + 0] = make_float4(position.x - displacement.x, position.y - displacement.y, position.z + displacement.z, 0.1f * position.x);
-    mine[3 * lane + 1] = make_float4(0.1f * position.y, tbn2.x, tbn2.y, tbn2.z);
-    mine[3 * lane + 2] = make_float4(tbn0.x, tbn0.y, tbn0.z, -1.0f);
-
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // the wave's 4 rows x 16 vertices = 4 x 48 float4: float4 number j belongs to row j / 48 of the wave
-    int const x0 = blockIdx.x * 16;
-    int const y0 = blockIdx.y * 16 + 4 * (int)(threadIdx.x >> 6);
-    int const rowlen = min(16, g.sizex - x0) * 3;                                // float4 of this tile in one mesh row
-
-    #pragma unroll
-    for(int k = 0; k < 3; ++k)
-    {
-      int const j = 64 * k + lane;
-      int const r = j / 48, c = j % 48;
-
-      if (c < rowlen && y0 + r < g.sizey)
-        reinterpret_cast<float4*>(g.vertices)[((size_t)(y0 + r) * g.sizex + x0) * 3 + c] = mine[j];
-    }
-  }
 }
