@@ -38,7 +38,16 @@ def parse():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--resolution", type=int, default=1024)
     ap.add_argument("--cascades", type=int, default=4)
-    ap.add_argument("--gather", choices=("batch", "none"), default="batch")
+    ap.add_argument("--gather", choices=("pipelined", "serial", "none"), default="pipelined",
+                    help="N > 1: the one all-gather per batch of --steps steps that reassembles the displacement field. pipelined: the collective "
+                         "of the previous batch runs on a second stream under this batch's kernels (double-buffered payload); serial: after the "
+                         "batch's last step, on the compute stream; none: left out")
+    ap.add_argument("--payload", choices=("xyz32", "xyz16", "maps"), default="xyz32",
+                    help="what a rank contributes to the all-gather: the displacement field as floats (12 B/pt, exact), as halves (8 B/pt), or both "
+                         "map layers (32 B/pt)")
+    ap.add_argument("--standin-peers", type=int, default=0,
+                    help="1 GPU only (overhead measurement): run the pack kernel and, on the second stream, the HBM writes of this many peers' payloads "
+                         "in place of the collective")
     ap.add_argument("--spectrum", choices=("fp32", "fp16"), default="fp32",
                     help="storage of the work spectrum between the two passes (fp16: BASELINE.json configs[4]; arithmetic stays fp32)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
@@ -149,16 +158,33 @@ def main():
     stream = torch.cuda.Stream(dev)   # a real (non-default) stream: events and RCCL below are ordered on it too
     torch.cuda.set_stream(stream)
     oc.set_stream(stream.cuda_stream)
-    gathered = torch.empty(world * maps.numel(), dtype=torch.float32, device=dev) if (world > 1 and args.gather == "batch") else None
+    # the all-gather of north_star (datum_amd/farm.py): payload packed by the module, double-buffered, collective on a second stream
+    gathering = (world > 1 and args.gather != "none") or args.standin_peers > 0
+    tg = None
+    if gathering:
+        code, pdtype, _ = farm.PAYLOADS[args.payload]
+        pbytes = oc.payload_bytes(code)
+        assert pbytes == farm.payload_bytes(N, C, args.payload)
+        tg = farm.TileGather(farm.payload_numel(N, C, args.payload), pdtype, dev, world, standin_peers=args.standin_peers)
 
     def step():
         oc.update(DT)
         oc.displace()
 
+    def pack():
+        buf = tg.acquire()
+        oc.pack_displacement(code, buf.data_ptr(), pbytes)
+
     for _ in range(args.warmup):
         step()
-    if gathered is not None:
-        farm.gather_maps(maps, world, out=gathered)
+    if gathering:
+        # one untimed round of the whole choreography (RCCL sets its channels up on first use), then the payload of the
+        # warm-up batch, ready to be gathered under the timed batch
+        pack()
+        tg.launch()
+        tg.result()
+        if args.gather == "pipelined":
+            pack()
 
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -167,18 +193,32 @@ def main():
 
     # kernel durations for the roofline: HIP events around the two kernels of every 8th step of the timed loop, on
     # the stream they run on (bracketing every step would cost ~10 % of the throughput being measured)
-    oc.profile_begin(args.steps, 8 if args.steps >= 16 else 1)
-    ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    stride = 8 if args.steps >= 16 else 1
+    oc.profile_begin((args.steps + stride - 1) // stride, stride)
+    ev0, ev1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
 
+    # The timed region holds exactly --steps steps, one pack and one all-gather.  pipelined: the gather is the PREVIOUS
+    # batch's (its payload was packed above), issued first and running on the communication stream while this batch's kernels
+    # run; this batch's payload is packed at the end and would be gathered under the next batch.  serial: this batch's own
+    # payload is packed and gathered after its last step.
     t0 = time.perf_counter()
     ev0.record(stream)
-    for _ in range(args.steps):
-        step()
+    if gathering and args.gather == "pipelined":
+        slot = tg.launch()
+        for _ in range(args.steps):
+            step()
+        pack()
+    elif gathering:
+        for _ in range(args.steps):
+            step()
+        pack()
+        slot = tg.launch()
+        tg.result()
+    else:
+        for _ in range(args.steps):
+            step()
     ev1.record(stream)
-    if gathered is not None:
-        farm.gather_maps(maps, world, out=gathered)
-    ev2.record(stream)
-    torch.cuda.synchronize(dev)
+    torch.cuda.synchronize(dev)      # both streams
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize(dev)
@@ -204,8 +244,8 @@ def main():
         gbytes = 48.0 * sx * sy + 32.0 * N * N
         gen = {"mesh": f"{sx}x{sy}", "ms": gms, "vertices_per_s": sx * sy / (gms * 1e-3), "GBps": gbytes / (gms * 1e-3) / 1e9,
                "bytes": gbytes, "finite": bool(torch.isfinite(verts).all())}
-    compute_ms = ev0.elapsed_time(ev1)
-    gather_ms = ev1.elapsed_time(ev2) if gathered is not None else 0.0
+    compute_ms = ev0.elapsed_time(ev1)     # the compute stream's share (serial: includes the gather it waits for)
+    gather_ms = tg.last_collective_ms(slot) if gathering else 0.0
 
     if world > 1:
         t = torch.tensor([elapsed, compute_ms, gather_ms], dtype=torch.float64, device=dev)
@@ -246,7 +286,12 @@ def main():
                 "resolution": N,
                 "cascades_per_gpu": C,
                 "grids_per_step": C * world,
-                "gather": args.gather if world > 1 else "n/a (1 GPU)",
+                "gather": (f"{args.gather}: one all-gather of the {args.payload} payload per {args.steps} steps, inside the timed region"
+                           + (" (the previous batch's, on a second stream under this batch's kernels)" if args.gather == "pipelined" else ""))
+                          if (world > 1 and args.gather != "none") else ("none" if world > 1 else
+                          (f"n/a (1 GPU; stand-in for {args.standin_peers} peers' payload writes on a second stream)" if args.standin_peers else "n/a (1 GPU)")),
+                "payload": args.payload if gathering else None,
+                "payload_bytes_per_rank": pbytes if gathering else None,
                 "parallelism": f"tile-farm x{world}",
             },
             "roofline": {
@@ -269,7 +314,7 @@ def main():
             "compute_ms": compute_ms,
             "gather_ms": gather_ms,
             "gen": gen,
-            "value_compute_only": grids / (compute_ms * 1e-3) if compute_ms > 0 else None,
+            "value_compute_only": grids / (compute_ms * 1e-3) if (compute_ms > 0 and args.gather != "serial") else None,
         }
 
         if world == 1 and args.cpu_seconds > 0:

@@ -21,6 +21,7 @@ SUPPORTED = (64, 128, 256, 512, 1024, 2048, 4096)
 MAX_CASCADES = 16
 
 OK, EINVAL, ESTATE, ENOMEM = 0, -1, -2, -3
+PAYLOAD_MAPS, PAYLOAD_XYZ32, PAYLOAD_XYZ16 = 0, 1, 2
 
 
 class OceanSet(ctypes.Structure):
@@ -64,6 +65,8 @@ SYMBOLS = {
     "datum_ocean_update": (I, [P, F]),
     "datum_ocean_displace": (I, [P]),
     "datum_ocean_gen": (I, [P, I, ctypes.POINTER(OceanSet), I, I, P]),
+    "datum_ocean_payload_bytes": (I, [P, I, ctypes.POINTER(ctypes.c_size_t)]),
+    "datum_ocean_pack_displacement": (I, [P, I, P, ctypes.c_size_t]),
     "datum_ocean_read_maps": (I, [P, I, P]),
     "datum_ocean_sync": (I, [P]),
     "datum_ocean_wait_event": (I, [P, P]),
@@ -209,6 +212,15 @@ class Ocean:
 
     def gen(self, cascade, oceanset, sizex, sizey, vertices_device_ptr):
         self._check(self.lib.datum_ocean_gen(self.h, cascade, ctypes.byref(oceanset), sizex, sizey, P(vertices_device_ptr)))
+
+    def payload_bytes(self, fmt):
+        n = ctypes.c_size_t()
+        self._check(self.lib.datum_ocean_payload_bytes(self.h, fmt, ctypes.byref(n)))
+        return n.value
+
+    def pack_displacement(self, fmt, device_ptr, nbytes):
+        """Enqueue the packing of every cascade's displacement into caller-owned device memory (all-gather payload)."""
+        self._check(self.lib.datum_ocean_pack_displacement(self.h, fmt, P(device_ptr), nbytes))
 
     def read_maps(self, cascade):
         out = np.empty((2, self.N, self.N, 4), np.float32)

@@ -796,6 +796,63 @@ int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, 
   return DATUM_OCEAN_OK;
 }
 
+int datum_ocean_payload_bytes(datum_ocean_t ctx, int format, size_t *bytes)
+{
+  if (!ctx || !bytes)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_payload_bytes: null argument");
+
+  size_t const points = (size_t)ctx->cascades * plane(ctx);
+
+  switch(format)
+  {
+    case DATUM_OCEAN_PAYLOAD_MAPS: *bytes = points * 2 * sizeof(float4); break;
+    case DATUM_OCEAN_PAYLOAD_XYZ32: *bytes = points * 12; break;
+    case DATUM_OCEAN_PAYLOAD_XYZ16: *bytes = points * 8; break;
+    default: return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_payload_bytes: unknown format");
+  }
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_pack_displacement(datum_ocean_t ctx, int format, void *payload_device, size_t bytes)
+{
+  if (!ctx || !payload_device)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_pack_displacement: null argument");
+
+  size_t need = 0;
+
+  int rc = datum_ocean_payload_bytes(ctx, format, &need);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  if (bytes < need)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_pack_displacement: payload buffer too small (datum_ocean_payload_bytes)");
+
+  if ((uintptr_t)payload_device & 15)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_pack_displacement: payload buffer must be 16-byte aligned");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  if (format == DATUM_OCEAN_PAYLOAD_MAPS)
+  {
+    // the map block as it lies in memory (device layout), so that the producer may go on writing its own buffer
+    HIPCHECK(ctx, hipMemcpyAsync(payload_device, ctx->maps, need, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  else
+  {
+    int const blocks = std::min<size_t>((size_t)ctx->cus * 8, ((size_t)ctx->cascades * plane(ctx) / 4 + 255) / 256);
+
+    if (format == DATUM_OCEAN_PAYLOAD_XYZ16)
+      hipLaunchKernelGGL(ocean_pack_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device);
+    else
+      hipLaunchKernelGGL(ocean_pack_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device);
+
+    HIPCHECK(ctx, hipGetLastError());
+  }
+
+  return DATUM_OCEAN_OK;
+}
+
 int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps)
 {
   if (!ctx || !maps)

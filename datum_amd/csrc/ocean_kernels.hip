@@ -996,6 +996,55 @@ namespace ocean
       atomicMax(result, __float_as_uint(m));
   }
 
+  //|---------------------- all-gather payload ---------------------------------
+  // What a rank sends to its peers when the tiles of a farm are reassembled: the displacement layer
+  // (dx, dy, dz) of every cascade, row-major [cascade][y][x], as three floats (12 B per point) or four halves
+  // (dx, dy, dz, 0: 8 B per point).  One thread per group of four texels: a 64-byte run in, 48 or 32 bytes out.
+
+  template<bool HALF>
+  __global__ void __launch_bounds__(256) ocean_pack_kernel(float4 const *maps, int N, int cascades, void *payload)
+  {
+    static_assert(MAP_GROUP == 4 || MAP_GROUP == 1, "the pack kernel reads four neighbouring texels of layer 0");
+
+    size_t const groups = (size_t)cascades * N * (N / 4);
+
+    for(size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x)
+    {
+      size_t const row = g / (N / 4);                 // cascade * N + y
+      int const x0 = (int)(g % (N / 4)) * 4;
+
+      float4 const *src = maps + row * 2 * N;         // map_index of (x, y = 0, layer 0) within this row
+
+      float4 t[4];
+
+      #pragma unroll
+      for(int k = 0; k < 4; ++k)
+        t[k] = src[map_index(N, 0, x0 + k, 0)];
+
+      if constexpr (HALF)
+      {
+        half4_ h[4];
+
+        #pragma unroll
+        for(int k = 0; k < 4; ++k)
+          h[k] = half4_{ (_Float16)t[k].x, (_Float16)t[k].y, (_Float16)t[k].z, (_Float16)0.0f };
+
+        float4 *dst = static_cast<float4*>(payload) + g * 2;
+
+        dst[0] = __builtin_bit_cast(float4, (half4_ const (&)[2])h[0]);
+        dst[1] = __builtin_bit_cast(float4, (half4_ const (&)[2])h[2]);
+      }
+      else
+      {
+        float4 *dst = static_cast<float4*>(payload) + g * 3;
+
+        dst[0] = make_float4(t[0].x, t[0].y, t[0].z, t[1].x);
+        dst[1] = make_float4(t[1].y, t[1].z, t[2].x, t[2].y);
+        dst[2] = make_float4(t[2].z, t[3].x, t[3].y, t[3].z);
+      }
+    }
+  }
+
   //|---------------------- spectrum rebuild (lerp_ocean_waves) ----------------
 
   // phillips(k, a, v, w) of ocean.cpp:89-107, same operation order

@@ -3,8 +3,18 @@
 Cascades and tiles are independent (OceanParams, N x N grid) problems -- own seed, no halo, each grid is periodic
 (data/ocean.map.comp:58) -- so rank r simply owns the global grids [r*C, (r+1)*C) and the displacement step needs no
 collective.  The one exchange north_star asks for, "a single RCCL all-gather over xGMI to reassemble the displacement
-field", is an all_gather_into_tensor of every rank's [C][2][N][N][4] float map block into a [world*C][2][N][N][4]
-buffer; this module holds the index arithmetic so that it can be tested on CPU with gloo.
+field", is ONE all_gather_into_tensor per batch of steps.  What is gathered (the payload) and when:
+
+  * payload: every rank packs its tiles' displacement into a flat buffer (datum_ocean_pack_displacement,
+    include/datum_ocean_hip.h): "xyz32" = (dx, dy, dz) as floats, 12 B per point, exact -- the displacement FIELD
+    north_star names; "xyz16" = the same as halves, 8 B per point; "maps" = both map layers as they lie in memory,
+    32 B per point.  xGMI is point to point (7 links x ~153 GB/s per GPU): at 8 ranks a 1024^2 x 4 block is 0.35 GB
+    received per rank as xyz32 against 0.94 GB as maps.
+  * overlap: the payload is double-buffered and the collective of batch k runs on a second stream while the kernels
+    of batch k + 1 run on the compute stream (TileGather below); event-ordered, no host synchronisation.
+
+This module holds the index arithmetic and the stream / buffer choreography so that both can be tested on CPU with
+gloo (tests/test_farm_gloo.py).  No compute happens here.
 """
 
 import torch
@@ -12,6 +22,13 @@ import torch.distributed as dist
 
 SEED_BASE = 1000  # std::mt19937(1000 + cascade_or_tile_index)
 CASCADE_WAVESCALES = (22.0, 64.0, 176.0, 512.0)
+
+# payload formats: name -> (code of include/datum_ocean_hip.h, torch dtype, elements per grid point)
+PAYLOADS = {
+    "maps": (0, torch.float32, 8),
+    "xyz32": (1, torch.float32, 3),
+    "xyz16": (2, torch.float16, 4),
+}
 
 
 def owned_grids(rank, world, grids_per_rank):
@@ -32,9 +49,17 @@ def map_block_numel(N, grids):
     return grids * 2 * N * N * 4
 
 
+def payload_numel(N, grids, fmt):
+    return grids * N * N * PAYLOADS[fmt][2]
+
+
+def payload_bytes(N, grids, fmt):
+    return payload_numel(N, grids, fmt) * torch.empty(0, dtype=PAYLOADS[fmt][1]).element_size()
+
+
 def gather_maps(local_maps, world, out=None):
-    """All-gather the per-rank map blocks (flat float32 tensors of equal size) into one flat tensor ordered by
-    global grid index.  One collective; with world == 1 it is a copy-free view."""
+    """All-gather the per-rank blocks (flat tensors of equal size) into one flat tensor ordered by global grid index.
+    One collective, on the current stream; with world == 1 it is a copy-free view."""
     if world == 1:
         return local_maps
     if out is None:
@@ -44,6 +69,141 @@ def gather_maps(local_maps, world, out=None):
 
 
 def view_grid(gathered, N, global_index):
-    """[2][N][N][4] view of one grid inside a gathered (or local) flat map buffer."""
+    """[2][N][N][4] view of one grid inside a gathered (or local) flat block of LOGICAL maps ([layer][y][x][4], what
+    datum_ocean_read_maps returns; the device layout of a bound map buffer is capi.map_layers' business)."""
     n = 2 * N * N * 4
     return gathered[global_index * n:(global_index + 1) * n].view(2, N, N, 4)
+
+
+def view_displacement(gathered, N, global_index, fmt):
+    """(dx, dy, dz) of one grid inside a gathered (or local) xyz32 / xyz16 payload: [N][N][3] view."""
+    assert fmt in ("xyz32", "xyz16")
+    per = PAYLOADS[fmt][2]
+    n = N * N * per
+    return gathered[global_index * n:(global_index + 1) * n].view(N, N, per)[..., :3]
+
+
+def pack_host(logical_maps, fmt):
+    """The payload datum_ocean_pack_displacement produces, built on the host from LOGICAL maps ([grids][2][N][N][4]).
+    Only the CPU tests use it (the oracle stands in for a rank's GPU there); "maps" is not offered because the device
+    layout of the map block is the kernels' own."""
+    disp = logical_maps[:, 0, :, :, :3]
+    if fmt == "xyz32":
+        return disp.contiguous().reshape(-1).to(torch.float32)
+    if fmt == "xyz16":
+        z = torch.zeros(disp.shape[:-1] + (1,), dtype=disp.dtype)
+        return torch.cat([disp, z], -1).to(torch.float16).reshape(-1)
+    raise ValueError(fmt)
+
+
+class TileGather:
+    """Double-buffered, overlapped all-gather of the ranks' payloads.
+
+    Two slots, each a payload buffer (this rank's contribution) and a gathered buffer (everybody's).  Per batch:
+
+        buf = tg.acquire()                  # slot's payload buffer; the producing stream first waits until the collective
+                                            # that last READ this slot has finished
+        ... enqueue the pack into buf on the producing (compute) stream ...
+        tg.launch()                         # the collective of this slot on the communication stream, ordered behind the
+                                            # pack by an event; returns at once, the next batch's kernels overlap it
+        ...
+        out = tg.result()                   # (any later time) the consuming stream waits for the oldest launched slot
+
+    On CUDA/HIP the ordering is by events between the producer's stream and an own communication stream; on CPU (gloo)
+    the collective is issued with async_op=True and result() waits on its handle.  world == 1: no collective, result()
+    returns the payload itself.
+    """
+
+    def __init__(self, numel, dtype, device, world, slots=2, standin_peers=0, force_collective=False):
+        # standin_peers (measurement aid, one GPU only): in place of the collective, the communication stream writes
+        # the payload `standin_peers` times into the gathered buffer -- the HBM writes of that many peers' tiles arriving
+        # -- so that the cost of the pack kernel plus a concurrently busy second stream can be measured without a node
+        # force_collective (tests): issue the collective in a one-rank process group too
+        assert standin_peers == 0 or world == 1
+        self.standin = standin_peers
+        self.world = world
+        self.collective = world > 1 or force_collective
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.payload = [torch.empty(numel, dtype=dtype, device=self.device) for _ in range(slots)]
+        parts = world if self.collective else (1 + standin_peers if standin_peers else 0)
+        self.gathered = [torch.empty(parts * numel, dtype=dtype, device=self.device) if parts else None for _ in range(slots)]
+        self.work = [None] * slots           # gloo: async handles
+        self.done = [None] * slots           # cuda: event recorded behind the slot's collective
+        self.head = 0                        # next slot to acquire
+        self.acquired = None
+        self.pending = []                    # launched, not yet handed out by result()
+        if self.cuda:
+            self.comm = torch.cuda.Stream(self.device)
+            self.packed = [torch.cuda.Event() for _ in range(slots)]
+            self.timing = [None] * slots     # (start, stop) events around the slot's last collective
+
+    def acquire(self):
+        assert self.acquired is None, "launch() the acquired slot first"
+        s = self.head
+        if self.cuda and self.done[s] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.done[s])   # WAR: the old collective still reads it
+        elif self.work[s] is not None:
+            self.work[s].wait()
+            self.work[s] = None
+        if s in self.pending:
+            self.pending.remove(s)           # its result was never asked for: overwritten by the new batch
+        self.acquired = s
+        return self.payload[s]
+
+    def launch(self):
+        s = self.acquired
+        assert s is not None, "acquire() first"
+        self.acquired = None
+        self.head = (s + 1) % len(self.payload)
+        if self.collective or self.standin:
+            if self.cuda:
+                self.packed[s].record(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self.comm):
+                    self.comm.wait_event(self.packed[s])
+                    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    start.record(self.comm)
+                    if self.collective:
+                        dist.all_gather_into_tensor(self.gathered[s], self.payload[s])
+                    else:
+                        n = self.payload[s].numel()
+                        for k in range(1, 1 + self.standin):
+                            self.gathered[s][k * n:(k + 1) * n].copy_(self.payload[s], non_blocking=True)
+                    stop.record(self.comm)
+                    self.done[s] = stop
+                    self.timing[s] = (start, stop)
+            else:
+                self.work[s] = dist.all_gather_into_tensor(self.gathered[s], self.payload[s], async_op=True)
+        self.pending.append(s)
+        return s
+
+    def result(self):
+        """Gathered buffer of the OLDEST launched batch (ordered by global grid index); the current stream waits for it."""
+        assert self.pending, "nothing launched"
+        s = self.pending.pop(0)
+        if not self.collective and not self.standin:
+            return self.payload[s]
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_event(self.done[s])
+        elif self.work[s] is not None:
+            self.work[s].wait()
+            self.work[s] = None
+        return self.gathered[s]
+
+    def last_collective_ms(self, slot):
+        """Duration of the slot's last collective on the communication stream (CUDA/HIP only, after it has finished)."""
+        if not self.cuda or self.timing[slot] is None:
+            return 0.0
+        a, b = self.timing[slot]
+        b.synchronize()
+        return a.elapsed_time(b)
+
+    def drain(self):
+        """Host-side wait for everything launched (end of a timed region)."""
+        if self.cuda:
+            self.comm.synchronize()
+        else:
+            for s, w in enumerate(self.work):
+                if w is not None:
+                    w.wait()
+                    self.work[s] = None

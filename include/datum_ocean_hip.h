@@ -131,6 +131,19 @@ int datum_ocean_displace(datum_ocean_t ctx);
  * cascade's displacement map.  sizex, sizey: multiples of 16 in the reference; any size >= 2 here. */
 int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, int sizex, int sizey, void *vertices_device);
 
+/* What a rank contributes when the tiles of a multi-GPU farm are reassembled with one all-gather (SURVEY.md 8e;
+ * nothing in the reference: it has one device).  Packs the displacement of every cascade of the handle into
+ * caller-owned DEVICE memory, enqueued on the handle's stream behind the last displace, so that the collective can
+ * read it on another stream while the next displace overwrites the maps:
+ *   MAPS   the whole map block as it lies in memory, both layers (32 B per point, device layout of bind_maps)
+ *   XYZ32  layer 0 only, [cascade][y][x] (dx, dy, dz) as three floats   (12 B per point, exact)
+ *   XYZ16  layer 0 only, [cascade][y][x] (dx, dy, dz, 0) as four halves  (8 B per point, round to nearest) */
+#define DATUM_OCEAN_PAYLOAD_MAPS 0
+#define DATUM_OCEAN_PAYLOAD_XYZ32 1
+#define DATUM_OCEAN_PAYLOAD_XYZ16 2
+int datum_ocean_payload_bytes(datum_ocean_t ctx, int format, size_t *bytes);
+int datum_ocean_pack_displacement(datum_ocean_t ctx, int format, void *payload_device, size_t bytes);
+
 /* blocking read-backs (host pointers).  maps: 2*N*N*4 floats. */
 int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps);
 

@@ -77,6 +77,90 @@ def test_two_rank_farm_and_gather():
         assert abs(float(np.abs(m[0, ..., 2].astype(np.float64)).sum()) - sums0[g]) < 1e-6 * max(1.0, sums0[g])
 
 
+def _pipeline_worker(rank, world, port, N, per_rank, fmt, batches, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from datum_amd import farm
+        from oracle import oracle
+
+        mine = farm.owned_grids(rank, world, per_rank)
+        states = []
+        for g in mine:
+            ws = farm.grid_wavescale(g, per_rank)
+            _, h0 = oracle.seed(N, farm.grid_seed(g), ws)
+            states.append((h0, np.zeros((N, N), np.float32), ws))
+        tg = farm.TileGather(farm.payload_numel(N, per_rank, fmt), farm.PAYLOADS[fmt][1], "cpu", world)
+        maps = torch.empty(per_rank, 2, N, N, 4)          # the rank's ONE map buffer, overwritten by every batch
+        got = []
+        for b in range(batches):
+            for i, (h0, phase, ws) in enumerate(states):  # "batch b": one more step of every owned grid
+                maps[i].copy_(torch.from_numpy(oracle.displace(h0, phase, ws, 1.35, dt=np.float32(1 / 60))))
+            tg.acquire().copy_(farm.pack_host(maps, fmt))
+            tg.launch()                                   # returns at once; the next batch overwrites `maps` meanwhile
+            if b >= 1:
+                out = tg.result()                         # batch b - 1
+                got.append([farm.view_displacement(out, N, g, fmt).float().clone() for g in range(world * per_rank)])
+        out = tg.result()
+        got.append([farm.view_displacement(out, N, g, fmt).float().clone() for g in range(world * per_rank)])
+        tg.drain()
+        q.put((rank, [[float(x.double().abs().sum()) for x in batch] for batch in got], [[x[N // 3, N // 5].tolist() for x in batch] for batch in got]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fmt", ["xyz32", "xyz16"])
+def test_pipelined_gather_double_buffer(fmt):
+    # TileGather: the collective of batch k is in flight while batch k + 1 is produced into the other slot and the
+    # single map buffer is overwritten; results come out in batch order, every rank sees every grid, and the payload
+    # layout ([grid][y][x] (dx, dy, dz) as floats, or (dx, dy, dz, 0) as halves) is what view_displacement reads
+    world, N, per_rank, batches = 2, 64, 2, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, N, per_rank, fmt, batches, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, sums0, probes0), (_, sums1, probes1) = res
+    assert len(sums0) == batches and sums0 == sums1 and probes0 == probes1      # both ranks reassembled identical fields
+
+    from datum_amd import farm
+    from oracle import oracle
+
+    tol = 1e-6 if fmt == "xyz32" else 2e-3
+    for g in range(world * per_rank):
+        ws = farm.grid_wavescale(g, per_rank)
+        _, h0 = oracle.seed(N, farm.grid_seed(g), ws)
+        phase = np.zeros((N, N), np.float32)
+        for b in range(batches):
+            m = oracle.displace(h0, phase, ws, 1.35, dt=np.float32(1 / 60))
+            want = m[0, ..., :3].astype(np.float64)
+            assert abs(np.abs(want).sum() - sums0[b][g]) < tol * np.abs(want).sum(), (b, g)       # batch b, not a neighbour of it
+            assert np.abs(want[N // 3, N // 5] - np.array(probes0[b][g])).max() < tol * max(1.0, np.abs(want).max())
+
+
+def test_tile_gather_single_rank_passthrough():
+    from datum_amd import farm
+
+    tg = farm.TileGather(12, torch.float32, "cpu", 1)
+    for k in range(3):
+        tg.acquire().fill_(float(k))
+        tg.launch()
+        assert float(tg.result()[0]) == float(k)
+    assert farm.payload_bytes(64, 2, "xyz32") == 2 * 64 * 64 * 12
+    assert farm.payload_bytes(64, 2, "xyz16") == 2 * 64 * 64 * 8
+    assert farm.payload_bytes(64, 2, "maps") == 2 * 64 * 64 * 32
+
+
 def test_single_rank_is_a_view():
     from datum_amd import farm
 

@@ -624,3 +624,93 @@ def test_random_parameters(capi, oracle, case):
                 assert np.abs(got[0][..., :3] - ref[0][..., :3]).max() < 10 * tol
                 assert rmse(got[0][..., :3], ref[0][..., :3]) < tol
                 assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 2e-5
+
+
+@pytest.mark.parametrize("N,C", [(64, 2), (256, 3)])
+def test_pack_displacement_payloads(capi, oracle, torch, N, C):
+    # the all-gather payloads (datum_ocean_pack_displacement): xyz32 is layer 0's (dx, dy, dz) bit for bit, xyz16 the same
+    # rounded to halves with a zero fourth component, maps the map block as it lies in memory; a short buffer is refused
+    from datum_amd import farm
+
+    p = oracle.EXAMPLE
+    with capi.Ocean(N, C) as oc:
+        for c in range(C):
+            oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c], p["choppiness"])
+            oc.upload_state(c, make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c]))
+        oc.update(DT)
+        oc.displace()
+        want = np.stack([oc.read_maps(c) for c in range(C)])
+        for fmt in ("xyz32", "xyz16", "maps"):
+            code, dtype, per = farm.PAYLOADS[fmt]
+            nbytes = oc.payload_bytes(code)
+            assert nbytes == farm.payload_bytes(N, C, fmt)
+            buf = torch.full((farm.payload_numel(N, C, fmt) + 16,), 7.0, dtype=dtype, device="cuda:0")
+            oc.pack_displacement(code, buf.data_ptr(), nbytes)
+            oc.sync()
+            got = buf.cpu()
+            assert bool((got[-16:] == 7.0).all())          # nothing written past the payload
+            if fmt == "maps":
+                for c in range(C):
+                    blk = got[c * 2 * N * N * 4:(c + 1) * 2 * N * N * 4].numpy()
+                    assert np.array_equal(capi.map_layers(blk, N), want[c])
+            else:
+                for c in range(C):
+                    d = farm.view_displacement(got[:-16], N, c, fmt)
+                    ref = torch.from_numpy(want[c, 0, ..., :3])
+                    assert torch.equal(d, ref if fmt == "xyz32" else ref.to(torch.float16))
+                if fmt == "xyz16":
+                    assert bool((got[:-16].view(-1, 4)[:, 3] == 0).all())
+            with pytest.raises(capi.OceanError) as e:
+                oc.pack_displacement(code, buf.data_ptr(), nbytes - 16)
+            assert e.value.code == capi.EINVAL
+
+
+def test_tile_gather_on_device(capi, oracle, torch):
+    # datum_amd/farm.TileGather on the GPU with a real RCCL collective (a one-rank process group: one box has one GPU):
+    # pack on the compute stream, all-gather on the communication stream, event-ordered, while the next batch's kernels
+    # overwrite the maps -- every batch's gathered displacement equals that batch's read-back
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from datum_amd import farm
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        N, C, fmt = 256, 2, "xyz32"
+        p = oracle.EXAMPLE
+        code, dtype, _ = farm.PAYLOADS[fmt]
+        stream = torch.cuda.Stream()
+        with capi.Ocean(N, C) as oc, torch.cuda.stream(stream):
+            oc.set_stream(stream.cuda_stream)
+            for c in range(C):
+                oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c], p["choppiness"])
+                oc.upload_state(c, make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c]))
+            tg = farm.TileGather(farm.payload_numel(N, C, fmt), dtype, "cuda:0", 1, force_collective=True)
+            nbytes = oc.payload_bytes(code)
+            want, got = [], []
+            for b in range(5):
+                for _ in range(3):
+                    oc.update(DT)
+                    oc.displace()
+                buf = tg.acquire()
+                oc.pack_displacement(code, buf.data_ptr(), nbytes)
+                tg.launch()
+                if b >= 1:
+                    got.append(tg.result().clone())          # batch b - 1, while batch b's collective is in flight
+                want.append(np.stack([oc.read_maps(c)[0, ..., :3] for c in range(C)]))   # (read-back syncs the compute stream only)
+            got.append(tg.result().clone())
+            tg.drain()
+            stream.synchronize()
+            oc.set_stream(None)
+        for b in range(5):
+            for c in range(C):
+                assert np.array_equal(farm.view_displacement(got[b].cpu(), N, c, fmt).numpy(), want[b][c]), (b, c)
+    finally:
+        dist.destroy_process_group()
