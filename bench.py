@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--payload", choices=("xyz32", "xyz16", "maps"), default="xyz32",
                     help="what a rank contributes to the all-gather: the displacement field as floats (12 B/pt, exact), as halves (8 B/pt), or both "
                          "map layers (32 B/pt)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="1 GPU only (plumbing check): take the N > 1 code path -- RCCL process group, pack, all-gather on the second stream, "
+                         "all-reduce of the timings -- in a one-rank group")
     ap.add_argument("--standin-peers", type=int, default=0,
                     help="1 GPU only (overhead measurement): run the pack kernel and, on the second stream, the HBM writes of this many peers' payloads "
                          "in place of the collective")
@@ -121,11 +124,13 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
+    multi = world > 1 or args.force_collective       # a process group exists and the collectives below are issued
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -159,13 +164,14 @@ def main():
     torch.cuda.set_stream(stream)
     oc.set_stream(stream.cuda_stream)
     # the all-gather of north_star (datum_amd/farm.py): payload packed by the module, double-buffered, collective on a second stream
-    gathering = (world > 1 and args.gather != "none") or args.standin_peers > 0
+    gathering = (multi and args.gather != "none") or args.standin_peers > 0
     tg = None
     if gathering:
         code, pdtype, _ = farm.PAYLOADS[args.payload]
         pbytes = oc.payload_bytes(code)
         assert pbytes == farm.payload_bytes(N, C, args.payload)
-        tg = farm.TileGather(farm.payload_numel(N, C, args.payload), pdtype, dev, world, standin_peers=args.standin_peers)
+        tg = farm.TileGather(farm.payload_numel(N, C, args.payload), pdtype, dev, world, standin_peers=args.standin_peers,
+                             force_collective=args.force_collective)
 
     def step():
         oc.update(DT)
@@ -187,7 +193,7 @@ def main():
             pack()
 
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -219,7 +225,7 @@ def main():
             step()
     ev1.record(stream)
     torch.cuda.synchronize(dev)      # both streams
-    if world > 1:
+    if multi:
         dist.barrier()
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
@@ -247,7 +253,7 @@ def main():
     compute_ms = ev0.elapsed_time(ev1)     # the compute stream's share (serial: includes the gather it waits for)
     gather_ms = tg.last_collective_ms(slot) if gathering else 0.0
 
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed, compute_ms, gather_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, compute_ms, gather_ms = (float(v) for v in t.tolist())
@@ -288,7 +294,7 @@ def main():
                 "grids_per_step": C * world,
                 "gather": (f"{args.gather}: one all-gather of the {args.payload} payload per {args.steps} steps, inside the timed region"
                            + (" (the previous batch's, on a second stream under this batch's kernels)" if args.gather == "pipelined" else ""))
-                          if (world > 1 and args.gather != "none") else ("none" if world > 1 else
+                          if (multi and args.gather != "none") else ("none" if multi else
                           (f"n/a (1 GPU; stand-in for {args.standin_peers} peers' payload writes on a second stream)" if args.standin_peers else "n/a (1 GPU)")),
                 "payload": args.payload if gathering else None,
                 "payload_bytes_per_rank": pbytes if gathering else None,
@@ -328,7 +334,7 @@ def main():
     oc.set_stream(None)
     oc.close()
 
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
