@@ -153,7 +153,8 @@ namespace
     void *args[] = { &a };
     void const *kernel = ctx->half ? reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, true>) : reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>);
 
-    return launch(kernel, dim3(RowCfg<N>::GROUPS, ctx->cascades), dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream, ev);
+    // work items = groups of row pairs x cascades, one workgroup each
+    return launch(kernel, dim3(RowCfg<N>::GROUPS * ctx->cascades), dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream, ev);
   }
 
   template<int N>
@@ -162,7 +163,16 @@ namespace
     void *args[] = { &a };
     void const *kernel = ctx->half ? reinterpret_cast<void const*>(&ocean_colpass_kernel<N, true>) : reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>);
 
-    return launch(kernel, dim3(ColCfg<N>::TILES, ctx->cascades), dim3(ColCfg<N>::THREADS), args, ColCfg<N>::LDS, ctx->stream, ev);
+    // work items = tiles x cascades; the large grids' workgroups are persistent, one per compute unit (the LDS of a
+    // 1024-thread tile fills a CU), and walk their share of the items
+#ifndef OCEAN_COL_WALK_GROUPS_PER_CU
+#define OCEAN_COL_WALK_GROUPS_PER_CU 1
+#endif
+    int const items = ColCfg<N>::TILES * ctx->cascades;
+    bool const walks = ctx->half ? col_walks<N, true>() : col_walks<N, false>();
+    int const groups = walks ? std::min(items, ctx->cus * OCEAN_COL_WALK_GROUPS_PER_CU) : items;
+
+    return launch(kernel, dim3(groups), dim3(ColCfg<N>::THREADS), args, ColCfg<N>::LDS, ctx->stream, ev);
   }
 
   #define DISPATCH_N(n, expr) \

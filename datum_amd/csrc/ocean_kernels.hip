@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "ocean_fft_core.h"
 #include "../../include/datum_ocean_hip.h"
 
@@ -80,10 +82,24 @@ namespace ocean
   #define OCEAN_WAIT_LOADS() do { } while(0)
 #endif
 
+#ifndef OCEAN_SPEC_BLOCK_ROWS
+#define OCEAN_SPEC_BLOCK_ROWS 8
+#endif
+#ifndef OCEAN_SPEC_BLOCK_COLS
+#define OCEAN_SPEC_BLOCK_COLS 8
+#endif
+  constexpr int SBR = OCEAN_SPEC_BLOCK_ROWS, SBC = OCEAN_SPEC_BLOCK_COLS;
+
+  // element index of grid point (y, x) in the blocked work spectrum: blocks of SBR rows x SBC columns, row-major inside
+  __host__ __device__ __forceinline__ constexpr size_t blocked_at(int N, int y, int x)
+  {
+    return ((size_t)(y / SBR) * (N / SBC) + (x / SBC)) * (SBR * SBC) + (y % SBR) * SBC + (x % SBC);
+  }
+
   template<int N>
   __host__ __device__ __forceinline__ constexpr size_t blocked(int y, int x)
   {
-    return ((size_t)((y >> 3) * (N / 8) + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7);
+    return blocked_at(N, y, x);
   }
 
   // Displacement map layout (private to this module: in the reference the map is a VK_IMAGE_TILING_OPTIMAL 2-layer
@@ -327,8 +343,12 @@ namespace ocean
   // K independent lines per thread go through the exchange phases together, so the number of barriers per
   // workgroup does not grow with K (one line per barrier phase is what the reference's per-field loop does).
 
-  template<int N, int K, int PS>
-  __device__ __forceinline__ void fft_lines(cf (&v)[K][Plan<N>::E], int t, cf *line, int linestride, cf const *midtab, typename LineTw<N>::type const &w, bool active)
+  struct NoHook { __device__ __forceinline__ void operator()() const { } };
+
+  // `before_last` runs between the last exchange and the last pass: every value of the lines is in LDS then and the
+  // threads' value registers are free (the walking column pass requests its next tile there)
+  template<int N, int K, int PS, typename Hook = NoHook>
+  __device__ __forceinline__ void fft_lines(cf (&v)[K][Plan<N>::E], int t, cf *line, int linestride, cf const *midtab, typename LineTw<N>::type const &w, bool active, Hook before_last = Hook())
   {
     typedef LineFFT<N, PS> L;
 
@@ -425,6 +445,8 @@ namespace ocean
       __syncthreads();
     }
 
+    before_last();
+
     if (active)
     {
       #pragma unroll
@@ -508,6 +530,11 @@ namespace ocean
     }
   }
 
+  // One group of row pairs per workgroup.  (Persistent workgroups that walk several pairs and request the next pair's
+  // inputs ahead -- what the column pass does from 2048^2 up -- were measured at 4096^2, where one 1024-thread workgroup
+  // fills a CU: the 48 registers of inputs in flight on top of the transforms' own exceed the 128 a thread may have there,
+  // hipcc spills, and a spill's reload waits for vmcnt(0), i.e. for the stores that should have drained meanwhile:
+  // 250 us against 181 us; walking without the prefetch: 180 us.  profiles/r02_large_grids.txt)
   template<int N, bool H16>
   __global__ void __launch_bounds__(RowCfg<N>::THREADS) ocean_rowpass_kernel(StepArgs a)
   {
@@ -518,7 +545,6 @@ namespace ocean
     constexpr int E = P::E;
     constexpr int T = P::T;
     constexpr int K = C::K;
-
     static_assert(E == 8 || E == 4, "slot_sine covers E = 4 and 8");
     static_assert(elem_in<N>(0, 1) == T && elem_out<N>(0, 1) == T, "slots are T columns apart");
 
@@ -529,54 +555,48 @@ namespace ocean
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
       midtab[i] = L::midtab_entry(a.tw, i);
 
-    // neighbouring pairs read each other's rows as ocean.sim's mirror rows: deal them to the same XCD
+    // work items = (cascade, group of PAIRS row pairs), cascade-major; workgroup b takes items b, b + gridDim.x, ...
+    // Neighbouring pairs read each other's rows as ocean.sim's mirror rows: item -> group deals contiguous bands of
+    // groups to the workgroups of one XCD (b % 8)
     constexpr int G = C::GROUPS;
-    int const grp = (G % 8 == 0) ? (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
 
-    int const cascade = blockIdx.y;
+    auto group_of = [&](int item) { int const q = item % G; return (G % 8 == 0) ? (q & 7) * (G / 8) + (q >> 3) : q; };
 
     int const pr = threadIdx.x / (2 * T);
     int const half = (threadIdx.x % (2 * T)) / T;
-    int const t = threadIdx.x % T;
-
-    int const p = grp * C::PAIRS + pr;                       // rows p and N - p; p = 0: rows 0 and N/2, each its own partner
-    int const y = half ? (p == 0 ? N / 2 : N - p) : p;
-    int const otherhalf = (p == 0) ? half : 1 - half;
-
-    cf *line = midtab + L::MIDTAB + (pr * 2 + half) * K * C::LINE;
-    cf *swap_out = line + C::LINE;
-    cf const *swap_in = midtab + L::MIDTAB + (pr * 2 + otherhalf) * K * C::LINE + C::LINE;
-
-    CascadeConst const cc = a.casc[cascade];
+    int const t_ = threadIdx.x % T;
 
     size_t const plane = (size_t)N * N;
 
-    float2 const *h0 = a.h0 + cascade * plane;
-    float const *omega = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
-
     constexpr int DBO = (int)(blocked<N>(0, T) - blocked<N>(0, 0));
 
-    static_assert(T % 8 == 0, "slots must be whole 8-column blocks apart");
+    static_assert(T % SBC == 0, "slots must be whole blocks apart");
 
-    __amdgpu_buffer_rsrc_t rphase = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
-    __amdgpu_buffer_rsrc_t rh0 = make_rsrc(h0, plane * sizeof(float2));
     typedef typename SpecValue<H16>::type SV;
-
-    __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV*>(a.spec) + cascade * plane, plane * sizeof(SV));
 
     bool const advance = a.ndt > 0;
 
-#ifdef OCEAN_STAMPS
-    unsigned long long *stampbase = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
-#endif
-    OCEAN_STAMP_WHERE();
-    OCEAN_STAMP(0);
+    // rows p and N - p of the item; p = 0: rows 0 and N/2, each its own partner
+    auto row_of = [&](int item) { int const p = group_of(item) * C::PAIRS + pr; return half ? (p == 0 ? N / 2 : N - p) : p; };
 
-    // inputs of ocean.sim: this row of phase and h0, the mirror row (sim.comp:59) backwards
-    float ph[E], om[E];
-    float2 hk[E], hm[E];
-
+    // inputs of ocean.sim: this row of phase and h0, the mirror row (sim.comp:59) backwards, the dispersion of the row
+    struct Inputs
     {
+      float ph[E], om[E];
+      float2 hk[E], hm[E];
+    };
+
+    auto request = [&](int item, int t, Inputs &in)
+    {
+      int const cascade = item / G;
+      int const y = row_of(item);
+
+      constexpr size_t QUAD = (size_t)(N / 2 + 1) * (N / 2 + 1);
+
+      __amdgpu_buffer_rsrc_t romega = make_rsrc(a.omega + cascade * QUAD, QUAD * sizeof(float));
+      __amdgpu_buffer_rsrc_t rphase = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
+      __amdgpu_buffer_rsrc_t rh0 = make_rsrc(a.h0 + cascade * plane, plane * sizeof(float2));
+
       int const e0 = y * N + t;
       int const m0 = (N - 1 - y) * N + (N - 1 - t - T * (E - 1));
 
@@ -584,13 +604,13 @@ namespace ocean
       for(int s = 0; s < E; ++s)
       {
 #ifdef OCEAN_ABLATE_ROWLOAD
-        ph[s] = 0.001f * (float)(t + T * s);
-        hk[s] = make_float2(0.01f * (float)((t + s) & 15), 0.02f);
-        hm[s] = make_float2(0.03f, 0.01f * (float)(y & 15));
+        in.ph[s] = 0.001f * (float)(t + T * s);
+        in.hk[s] = make_float2(0.01f * (float)((t + s) & 15), 0.02f);
+        in.hm[s] = make_float2(0.03f, 0.01f * (float)(y & 15));
 #else
-        ph[s] = buf_load_f32(rphase, e0 * 4, T * s * 4);
-        hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
-        hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
+        in.ph[s] = buf_load_f32(rphase, e0 * 4, T * s * 4);
+        in.hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
+        in.hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
 #endif
       }
 
@@ -599,120 +619,167 @@ namespace ocean
         #pragma unroll
         for(int s = 0; s < E; ++s)
 #ifdef OCEAN_ABLATE_ROWLOAD
-          om[s] = 1.0f + 0.001f * (float)s;
+          in.om[s] = 1.0f + 0.001f * (float)s;
 #else
-          om[s] = dispersion_lookup(omega, t + T * s, y, N);
+        {
+          // dispersion_lookup (ocean_omega_kernel's quadrant table) through the buffer path
+          int const j = abs(t + T * s - N / 2), i = abs(y - N / 2);
+
+          in.om[s] = buf_load_f32(romega, (i * (N / 2 + 1) + j) * 4, 0);
+        }
 #endif
       }
-    }
+    };
 
-    cf const ca = a.tw[t];                  // exp(2 pi i t / N)
+    cf const ca_ = a.tw[t_];                  // exp(2 pi i t / N)
 
-    typename LineTw<N>::type w;
-    LineTw<N>::load(a.tw, t, w);
+    typename LineTw<N>::type w_;
+    LineTw<N>::load(a.tw, t_, w_);
 
-    OCEAN_WAIT_LOADS();
-    OCEAN_STAMP(1);
+#ifdef OCEAN_STAMPS
+    unsigned long long *stampbase = a.stamps + (size_t)blockIdx.x * 16;
+#endif
+    OCEAN_STAMP_WHERE();
+    OCEAN_STAMP(0);
 
-    // update_ocean (ocean.cpp:223-233), each pending dt in turn
-    if (advance)
     {
-      for(int k = 0; k < a.ndt; ++k)
+      int const item = (int)blockIdx.x;
+      int const t = t_;
+      cf const ca = ca_;
+      typename LineTw<N>::type const &w = w_;
+
+      Inputs in;
+
+      request(item, t, in);
+
+      OCEAN_WAIT_LOADS();
+      OCEAN_STAMP(1);
+
+      int const cascade = item / G;
+      int const p = group_of(item) * C::PAIRS + pr;
+      int const y = row_of(item);
+      int const otherhalf = (p == 0) ? half : 1 - half;
+
+      cf *line = midtab + L::MIDTAB + (pr * 2 + half) * K * C::LINE;
+      cf *swap_out = line + C::LINE;
+      cf const *swap_in = midtab + L::MIDTAB + (pr * 2 + otherhalf) * K * C::LINE + C::LINE;
+
+      CascadeConst const cc = a.casc[cascade];
+
+      __amdgpu_buffer_rsrc_t rphase = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
+      __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV*>(a.spec) + cascade * plane, plane * sizeof(SV));
+
+      float ph[E];
+      float2 hk[E], hm[E];
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
       {
-        float const dt = a.dt[k];
+        ph[s] = in.ph[s];
+        hk[s] = in.hk[s];
+        hm[s] = in.hm[s];
+      }
+
+      // update_ocean (ocean.cpp:223-233), each pending dt in turn
+      if (advance)
+      {
+        for(int k = 0; k < a.ndt; ++k)
+        {
+          float const dt = a.dt[k];
+
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+            ph[s] = advance_phase_fast(ph[s], in.om[s] * dt);
+        }
 
         #pragma unroll
         for(int s = 0; s < E; ++s)
-          ph[s] = advance_phase_fast(ph[s], om[s] * dt);
+        {
+#ifdef OCEAN_ABLATE_ROWSTORE
+          if (ph[s] == 123456.789f)
+#endif
+          buf_store_f32_aux<OCEAN_PHASE_STORE_AUX>(ph[s], rphase, (y * N + t) * 4, T * s * 4);
+        }
       }
+
+      // ocean.sim once per point; the value goes to the thread that holds the negated index
+      cf h[E];
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+        h[s] = sim_height_products(hk[s], hm[s], ph[s]);
+
+        swap_out[padidx<C::PS>(t + T * s)] = h[s];
+      }
+
+      __syncthreads();
+
+      OCEAN_STAMP(2);
+
+      float const ky = wavevector(y, N, cc.scale);
+
+      // k^ keeps its sign where the index is its own negative (x = 0, y = 0): there the partner enters hx / hy negated
+      float const cy = (y == 0) ? -2.0f : 0.0f;
+      float const cx = (t == 0) ? -2.0f : 0.0f;
+
+      cf v[K][E];
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+        int const x = t + T * s;
+
+        cf n = swap_in[padidx<C::PS>((N - x) & (N - 1))];
+
+        cf const b = cf{ n.x, -n.y };                                   // conj(h~[-k])
+
+        float const kx = wavevector(x, N, cc.scale);
+        float const kinv = kinv_fast(kx, ky);
+        float const khx = kx * kinv, khy = ky * kinv;
+
+        // TWICE the Hermitian parts (the column pass folds the 1/2 into its sign factor): of h~, and of h~ as it enters hx, hy
+        cf const hh = cf{ h[s].x + b.x, h[s].y + b.y };
+        cf const hhx = (s == 0) ? cf{ fmaf(cx, b.x, hh.x), fmaf(cx, b.y, hh.y) } : hh;
+        cf const hhy = cf{ fmaf(cy, b.x, hh.x), fmaf(cy, b.y, hh.y) };
+
+        float const s2 = 2.0f * slot_sine<E>(ca, s);                    // 2 sin(2 pi x / N)
+
+        // C = h_H + i (-i k^x hhx) = h_H + k^x hhx ;  D = -i k^y hhy + 2 sin(theta) h_H
+        v[0][s] = cf{ fmaf(khx, hhx.x, hh.x), fmaf(khx, hhx.y, hh.y) };
+        v[1][s] = cf{ fmaf(khy, hhy.y, s2 * hh.x), fmaf(-khy, hhy.x, s2 * hh.y) };
+      }
+
+      // every thread has fetched its partner values before pass 0 overwrites the lines
+      __syncthreads();
+
+      OCEAN_STAMP(3);
+
+#ifndef OCEAN_ABLATE_ROWFFT
+      fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
+#endif
+
+      OCEAN_STAMP(4);
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
 #ifdef OCEAN_ABLATE_ROWSTORE
-        if (ph[s] == 123456.789f)
+        if (v[0][s].x == 123456.789f)
 #endif
-        buf_store_f32_aux<OCEAN_PHASE_STORE_AUX>(ph[s], rphase, (y * N + t) * 4, T * s * 4);
+        if constexpr (H16)
+        {
+          // round to nearest even; the host picks specscale so that no row sum can overflow (ocean_capi: spectrum_scale)
+          half4_ const hv = { (_Float16)(v[0][s].x * cc.specscale), (_Float16)(v[0][s].y * cc.specscale), (_Float16)(v[1][s].x * cc.specscale), (_Float16)(v[1][s].y * cc.specscale) };
+
+          buf_store_cf_aux<OCEAN_SPEC_STORE_AUX>(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
+        }
+        else
+          buf_store_f32x4_aux<OCEAN_SPEC_STORE_AUX>(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
       }
+
+      OCEAN_STAMP(5);
     }
-
-    // ocean.sim once per point; the value goes to the thread that holds the negated index
-    cf h[E];
-
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-    {
-      h[s] = sim_height_products(hk[s], hm[s], ph[s]);
-
-      swap_out[padidx<C::PS>(t + T * s)] = h[s];
-    }
-
-    __syncthreads();
-
-    OCEAN_STAMP(2);
-
-    float const ky = wavevector(y, N, cc.scale);
-
-    // k^ keeps its sign where the index is its own negative (x = 0, y = 0): there the partner enters hx / hy negated
-    float const cy = (y == 0) ? -2.0f : 0.0f;
-    float const cx = (t == 0) ? -2.0f : 0.0f;
-
-    cf v[K][E];
-
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-    {
-      int const x = t + T * s;
-
-      cf n = swap_in[padidx<C::PS>((N - x) & (N - 1))];
-
-      cf const b = cf{ n.x, -n.y };                                   // conj(h~[-k])
-
-      float const kx = wavevector(x, N, cc.scale);
-      float const kinv = kinv_fast(kx, ky);
-      float const khx = kx * kinv, khy = ky * kinv;
-
-      // TWICE the Hermitian parts (the column pass folds the 1/2 into its sign factor): of h~, and of h~ as it enters hx, hy
-      cf const hh = cf{ h[s].x + b.x, h[s].y + b.y };
-      cf const hhx = (s == 0) ? cf{ fmaf(cx, b.x, hh.x), fmaf(cx, b.y, hh.y) } : hh;
-      cf const hhy = cf{ fmaf(cy, b.x, hh.x), fmaf(cy, b.y, hh.y) };
-
-      float const s2 = 2.0f * slot_sine<E>(ca, s);                    // 2 sin(2 pi x / N)
-
-      // C = h_H + i (-i k^x hhx) = h_H + k^x hhx ;  D = -i k^y hhy + 2 sin(theta) h_H
-      v[0][s] = cf{ fmaf(khx, hhx.x, hh.x), fmaf(khx, hhx.y, hh.y) };
-      v[1][s] = cf{ fmaf(khy, hhy.y, s2 * hh.x), fmaf(-khy, hhy.x, s2 * hh.y) };
-    }
-
-    // every thread has fetched its partner values before pass 0 overwrites the lines
-    __syncthreads();
-
-    OCEAN_STAMP(3);
-
-#ifndef OCEAN_ABLATE_ROWFFT
-    fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
-#endif
-
-    OCEAN_STAMP(4);
-
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-    {
-#ifdef OCEAN_ABLATE_ROWSTORE
-      if (v[0][s].x == 123456.789f)
-#endif
-      if constexpr (H16)
-      {
-        // round to nearest even; the host picks specscale so that no row sum can overflow (ocean_capi: spectrum_scale)
-        half4_ const hv = { (_Float16)(v[0][s].x * cc.specscale), (_Float16)(v[0][s].y * cc.specscale), (_Float16)(v[1][s].x * cc.specscale), (_Float16)(v[1][s].y * cc.specscale) };
-
-        buf_store_cf_aux<OCEAN_SPEC_STORE_AUX>(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
-      }
-      else
-        buf_store_f32x4_aux<OCEAN_SPEC_STORE_AUX>(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
-    }
-
-    OCEAN_STAMP(5);
   }
 
   template<int N>
@@ -750,12 +817,22 @@ namespace ocean
     static_assert(OFF_MAIN % 16 == 0, "LDS carve must stay 16-byte aligned");
   };
 
-  // One tile per workgroup.  (A persistent variant -- workgroups walking a run of tiles, the next tile's values
-  // requested ahead and the map stores draining behind -- was measured 15 % slower: this pass runs at the rate the
-  // memory system moves its 48 B/pt, and queueing more requests per workgroup only delays the first ones.)
+  // N <= 1024: one tile per workgroup (2-4 workgroups per CU overlap each other's memory and arithmetic phases; a
+  // persistent variant was measured 15 % slower there).  N >= 2048: one 1024-thread workgroup fills a CU (LDS) and its
+  // phases -- 8 loads per thread, the transforms, 16 stores per thread -- ran one after the other (4096^2: 64 us of
+  // transforms + 72 us of loads + 110 us of stores = the 247 us measured).  There the workgroups are persistent: each
+  // walks a run of tiles, requests the next tile's values before transforming the current one and lets the current
+  // tile's stores drain under the next tile's transforms.
 #ifndef OCEAN_COL_MINBLOCKS
 #define OCEAN_COL_MINBLOCKS 1
 #endif
+#ifndef OCEAN_COL_WALK_FROM
+#define OCEAN_COL_WALK_FROM 2048
+#endif
+
+  // measured (profiles/r02_large_grids.txt): 2048^2 x 4 208 -> 187 us, 4096^2 with the fp16-stored spectrum 214 -> 196 us,
+  // 4096^2 fp32 248 -> 259 us (126 registers of the 128 a thread may have there): not walked
+  template<int N, bool H16> constexpr bool col_walks() { return N >= OCEAN_COL_WALK_FROM && (H16 || N < 4096); }
 
   template<int N, bool H16>
   __global__ void __launch_bounds__(ColCfg<N>::THREADS, OCEAN_COL_MINBLOCKS) ocean_colpass_kernel(StepArgs a)
@@ -768,6 +845,7 @@ namespace ocean
     constexpr int T = P::T;
     constexpr int W = C::W;
     constexpr int K = C::K;
+    constexpr bool WALK = col_walks<N, H16>();
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -778,174 +856,279 @@ namespace ocean
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
       midtab[i] = L::midtab_entry(a.tw, i);
 
-    // tiles narrower than an 8-column block share its cache lines with their neighbours: contiguous bands per XCD
     constexpr int NT = C::TILES;
-    int const tile = (NT % 8 == 0) ? (int)(blockIdx.x & 7) * (NT / 8) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-
-    int const cascade = blockIdx.y;
-
-    CascadeConst const cc = a.casc[cascade];
 
     size_t const plane = (size_t)N * N;
 
-    int const cp = threadIdx.x % W;
-    int const t = threadIdx.x / W;
-    int const x = tile * W + cp;
+    int const cp_ = threadIdx.x % W;
+    int const t_ = threadIdx.x / W;
 
     constexpr int DBI = (int)(blocked<N>(T, 0) - blocked<N>(0, 0));      // blocked spectrum, slot to slot (elements)
 
-    static_assert(T % 8 == 0, "slots must be whole 8-row blocks apart");
+    static_assert(T % SBR == 0, "slots must be whole blocks apart");
 
     typedef typename SpecValue<H16>::type SV;
+    typedef typename std::conditional<H16, cf, float4>::type Raw;        // one point of the work spectrum as loaded
 
-    __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV const*>(a.spec) + cascade * plane, plane * sizeof(SV));
-    __amdgpu_buffer_rsrc_t rmaps = make_rsrc(a.maps + (size_t)cascade * 2 * plane, 2 * plane * sizeof(float4));
+    // work items = (cascade, tile), cascade-major; workgroup b takes items b, b + gridDim.x, ...  Tiles narrower than a
+    // block of the spectrum share its cache lines with their neighbours: item -> tile deals contiguous bands of tiles to
+    // the workgroups of one XCD (b % 8), so that neighbours run there at the same time
+    int const items = NT * a.cascades;
+
+    auto tile_of = [&](int item) { int const q = item % NT; return (NT % 8 == 0) ? (q & 7) * (NT / 8) + (q >> 3) : q; };
+
+    auto request = [&](int item, int t, int cp, Raw (&q)[E])
+    {
+      int const cascade = item / NT;
+      int const x = tile_of(item) * W + cp;
+
+      __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV const*>(a.spec) + cascade * plane, plane * sizeof(SV));
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+#ifdef OCEAN_ABLATE_COLLOAD
+        if constexpr (H16)
+          q[s] = cf{ 0.01f * (float)((t + s) & 31), 0.02f * (float)s };
+        else
+          q[s] = make_float4(0.01f * (float)((t + s) & 31), 0.02f * (float)s, 0.03f, 0.01f * (float)cp);
+#else
+        if constexpr (H16)
+          q[s] = buf_load_cf(rspec, (int)blocked<N>(t, x) * 8, DBI * s * 8);
+        else
+          q[s] = buf_load_f32x4_aux<OCEAN_SPEC_LOAD_AUX>(rspec, (int)blocked<N>(t, x) * 16, DBI * s * 16);
+#endif
+      }
+    };
+
+    auto unpack = [&](Raw const (&q)[E], cf (&v)[2][E])
+    {
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+        if constexpr (H16)
+        {
+          half4_ const hv = __builtin_bit_cast(half4_, q[s]);
+
+          v[0][s] = cf{ (float)hv.x, (float)hv.y };
+          v[1][s] = cf{ (float)hv.z, (float)hv.w };
+        }
+        else
+        {
+          v[0][s] = cf{ q[s].x, q[s].y };
+          v[1][s] = cf{ q[s].z, q[s].w };
+        }
+      }
+    };
 
 #ifdef OCEAN_STAMPS
-    unsigned long long *stampbase = a.stamps + ((size_t)65536 + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+    unsigned long long *stampbase = a.stamps + ((size_t)65536 + blockIdx.x) * 16;
 #endif
     OCEAN_STAMP_WHERE();
     OCEAN_STAMP(0);
 
-    float4 q[E];
+    typename LineTw<N>::type w_;
+    LineTw<N>::load(a.tw, t_, w_);
 
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
+    // One tile: `q` holds its values as loaded; when `more`, the next tile's values are requested into `q` again between
+    // the last exchange and the last pass (registers are free there) and are in flight during the last pass, the map
+    // arithmetic and this tile's 16 stores, which then drain under the next tile's transforms.  The wait for those loads
+    // stands at the top of the next tile: the loads are OLDER than the stores, so a counted wait (vmcnt = the stores
+    // issued since) does not wait for the stores.  hipcc counts such a wait only if every path into it has the same
+    // history, hence the first tile is peeled off the loop below.
+    auto one_tile = [&](int item, Raw (&q)[E], bool more, int next)
     {
-#ifdef OCEAN_ABLATE_COLLOAD
-      q[s] = make_float4(0.01f * (float)((t + s) & 31), 0.02f * (float)s, 0.03f, 0.01f * (float)cp);
-#else
-      if constexpr (H16)
+      // Inside the walking loop everything derived from the thread's coordinates -- LDS addresses of every pass, store
+      // offsets, twiddle powers -- is loop invariant, and hipcc hoists it all out of the loop and keeps it in registers
+      // (128 VGPRs and spills against 70 for one tile; a spill's reload waits for vmcnt(0), i.e. for the very stores
+      // that should drain under the next tile).  Opaque copies of the coordinates make that work belong to the tile.
+      int t = t_, cp = cp_;
+
+      if constexpr (WALK)
+        asm volatile("" : "+v"(t), "+v"(cp));
+
+      // (the per-thread twiddles stay in registers across tiles: a load issued here would be younger than the previous
+      // tile's stores, and waiting for it would wait for them)
+      typename LineTw<N>::type w = w_;
+
+      if constexpr (WALK)
       {
-        half4_ const hv = __builtin_bit_cast(half4_, buf_load_cf(rspec, (int)blocked<N>(t, x) * 8, DBI * s * 8));
+        #pragma unroll
+        for(int k = 0; k < LineTw<N>::type::NMIDREG; ++k)
+          asm volatile("" : "+v"(w.mid[k].x), "+v"(w.mid[k].y));
 
-        q[s] = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
+        #pragma unroll
+        for(int m = 0; m < P::M; ++m)
+          asm volatile("" : "+v"(w.last[m].x), "+v"(w.last[m].y));
       }
-      else
-        q[s] = buf_load_f32x4_aux<OCEAN_SPEC_LOAD_AUX>(rspec, (int)blocked<N>(t, x) * 16, DBI * s * 16);
+
+      cf v[2][E];
+
+      unpack(q, v);
+
+      auto prefetch = [&]()
+      {
+#ifndef OCEAN_COL_NO_PREFETCH
+        if constexpr (WALK)
+        {
+          if (more)
+            request(next, t, cp, q);
+        }
 #endif
-    }
-
-    typename LineTw<N>::type w;
-    LineTw<N>::load(a.tw, t, w);
-
-    OCEAN_WAIT_LOADS();
-    OCEAN_STAMP(1);
-
-    cf v[2][E];
-
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-    {
-      v[0][s] = cf{ q[s].x, q[s].y };
-      v[1][s] = cf{ q[s].z, q[s].w };
-    }
+      };
 
 #ifndef OCEAN_ABLATE_COLFFT
-    if constexpr (K == 2)
-      fft_lines<N, 2, C::PS>(v, t, lines + cp * C::CS, W * C::CS, midtab, w, true);    // lines [K][W][CS]: columns CS apart as tuned for bank spread
-    else
-    {
-      #pragma unroll
-      for(int f = 0; f < 2; ++f)
+      if constexpr (K == 2)
+        fft_lines<N, 2, C::PS>(v, t, lines + cp * C::CS, W * C::CS, midtab, w, true, prefetch);    // lines [K][W][CS]: columns CS apart as tuned for bank spread
+      else
       {
-        cf u[1][E];
-
         #pragma unroll
-        for(int s = 0; s < E; ++s)
-          u[0][s] = v[f][s];
+        for(int f = 0; f < 2; ++f)
+        {
+          cf u[1][E];
 
-        fft_lines<N, 1, C::PS>(u, t, lines + cp * C::CS, C::CS, midtab, w, true);
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+            u[0][s] = v[f][s];
 
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-          v[f][s] = u[0][s];
+          if (f == 1)
+            fft_lines<N, 1, C::PS>(u, t, lines + cp * C::CS, C::CS, midtab, w, true, prefetch);
+          else
+            fft_lines<N, 1, C::PS>(u, t, lines + cp * C::CS, C::CS, midtab, w, true);
+
+          #pragma unroll
+          for(int s = 0; s < E; ++s)
+            v[f][s] = u[0][s];
+        }
       }
-    }
+#else
+      prefetch();
 #endif
 
-    OCEAN_STAMP(2);
+      OCEAN_STAMP(2);
 
-    // (-1)^(x+y) of map.comp:60; a thread's rows differ by even amounts
-    // times the 1/2 of the Hermitian parts, which the row pass leaves out
-    float const sig = (((x + t) & 1) ? -0.5f : 0.5f) * cc.specinv;
-    float const sigchop = sig * cc.choppiness;
+      int const cascade = item / NT;
+      int const x = tile_of(item) * W + cp;
 
-    // the transform lines are free after the last barrier of fft_lines: heights of this column for the y slope
-    float *own = dzmain + cp * C::SY;
+      CascadeConst const cc = a.casc[cascade];
 
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-      own[t + T * s] = v[0][s].x * sig;
+      __amdgpu_buffer_rsrc_t rmaps = make_rsrc(a.maps + (size_t)cascade * 2 * plane, 2 * plane * sizeof(float4));
 
-    __syncthreads();
+      // (-1)^(x+y) of map.comp:60; a thread's rows differ by even amounts
+      // times the 1/2 of the Hermitian parts, which the row pass leaves out
+      float const sig = (((x + t) & 1) ? -0.5f : 0.5f) * cc.specinv;
+      float const sigchop = sig * cc.choppiness;
 
-    OCEAN_STAMP(3);
+      // the transform lines are free after the last barrier of fft_lines: heights of this column for the y slope
+      float *own = dzmain + cp * C::SY;
 
-    float const nz = cc.nz;
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+        own[t + T * s] = v[0][s].x * sig;
 
-    int const o0 = (int)map_index(N, t, x, 0) * 16;   // byte offset of this thread's first texel (layer 0; layer 1 is 16 MAP_GROUP bytes on)
+      __syncthreads();
 
-    // line stores (four-column tiles): this lane's 16 bytes of row (t & ~1) and of row (t | 1): the even quad writes
-    // the displacement half of either line, the odd quad the normal half
-    int const olo = (int)map_index(N, t & ~1, x, t & 1) * 16;
-    int const ohi = (int)map_index(N, t | 1, x, t & 1) * 16;
+      OCEAN_STAMP(3);
 
-    #pragma unroll
-    for(int s = 0; s < E; ++s)
-    {
-      int const y = t + T * s;
+      float const nz = cc.nz;
 
-      // displacement (map.comp:62-64) and central-difference normal (map.comp:72-77)
-      float const dz = v[0][s].x * sig;
-      float const dx = v[0][s].y * sigchop;
-      float const dy = v[1][s].x * sigchop;
+      int const o0 = (int)map_index(N, t, x, 0) * 16;   // byte offset of this thread's first texel (layer 0; layer 1 is 16 MAP_GROUP bytes on)
 
-      float const nx = -(v[1][s].y * sig);
-      float const ny = own[(y + 1) & (N - 1)] - own[(y + N - 1) & (N - 1)];
-      float const inv = rsqrtf(nx * nx + ny * ny + nz * nz);
+      // line stores (four-column tiles): this lane's 16 bytes of row (t & ~1) and of row (t | 1): the even quad writes
+      // the displacement half of either line, the odd quad the normal half
+      int const olo = (int)map_index(N, t & ~1, x, t & 1) * 16;
+      int const ohi = (int)map_index(N, t | 1, x, t & 1) * 16;
+
+      #pragma unroll
+      for(int s = 0; s < E; ++s)
+      {
+        int const y = t + T * s;
+
+        // displacement (map.comp:62-64) and central-difference normal (map.comp:72-77)
+        float const dz = v[0][s].x * sig;
+        float const dx = v[0][s].y * sigchop;
+        float const dy = v[1][s].x * sigchop;
+
+        float const nx = -(v[1][s].y * sig);
+        float const ny = own[(y + 1) & (N - 1)] - own[(y + N - 1) & (N - 1)];
+        float const inv = rsqrtf(nx * nx + ny * ny + nz * nz);
 
 #ifdef OCEAN_ABLATE_COLSTORE
-      if (nx * inv + dx + dy == 123456.789f)
+        if (nx * inv + dx + dy == 123456.789f)
 #endif
-      {
-        // (at 4096^2, where the 537 MB of maps are far beyond the Infinity Cache, writing through costs 2x: 487-525 us
-        // against 250-260 us, with 32-byte runs of 2-column tiles and with 64-byte runs of two columns per thread alike)
-        constexpr int MAPAUX = (N <= 2048) ? OCEAN_MAP_STORE_AUX : 0;
+        {
+          // (at 4096^2, where the 537 MB of maps are far beyond the Infinity Cache, writing through costs 2x: 487-525 us
+          // against 250-260 us, with 32-byte runs of 2-column tiles and with 64-byte runs of two columns per thread alike)
+#ifndef OCEAN_MAP_STORE_AUX_BIG
+#define OCEAN_MAP_STORE_AUX_BIG 0
+#endif
+          constexpr int MAPAUX = (N <= 2048) ? OCEAN_MAP_STORE_AUX : OCEAN_MAP_STORE_AUX_BIG;
 
 #ifndef OCEAN_COL_LINE_STORES
 #define OCEAN_COL_LINE_STORES 1
 #endif
-        if constexpr (OCEAN_COL_LINE_STORES && W == 4 && MAP_GROUP == 4)
-        {
-          // Lanes 4 k .. 4 k + 3 of a wave hold the four texels of row t, the next four lanes those of row t + 1.  The
-          // two rows trade halves (DPP row shifts by four lanes), so that ONE store instruction writes a row's whole
-          // 128-byte line -- 64 bytes of displacement from the even quad, 64 bytes of normal from the odd quad -- instead of
-          // two instructions writing one half each (written through, half lines cost 24 us per 134 MB against 19-20 us).
-          float const dsp[3] = { dx, dy, dz }, nrm[3] = { nx * inv, ny * inv, nz * inv };
-          float lo[3], hi[3];
-
-          #pragma unroll
-          for(int k = 0; k < 3; ++k)
+          if constexpr (OCEAN_COL_LINE_STORES && W == 4 && MAP_GROUP == 4)
           {
-            // row of the even quad: its own displacement | the normal of the even quad, fetched by the odd quad from four lanes down
-            lo[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, dsp[k]), __builtin_bit_cast(int, nrm[k]), 0x114, 0xF, 0xA, false));
-            // row of the odd quad: the displacement of the odd quad, fetched by the even quad from four lanes up | its own normal
-            hi[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, nrm[k]), __builtin_bit_cast(int, dsp[k]), 0x104, 0xF, 0x5, false));
-          }
+            // Lanes 4 k .. 4 k + 3 of a wave hold the four texels of row t, the next four lanes those of row t + 1.  The
+            // two rows trade halves (DPP row shifts by four lanes), so that ONE store instruction writes a row's whole
+            // 128-byte line -- 64 bytes of displacement from the even quad, 64 bytes of normal from the odd quad -- instead of
+            // two instructions writing one half each (written through, half lines cost 24 us per 134 MB against 19-20 us).
+            float const dsp[3] = { dx, dy, dz }, nrm[3] = { nx * inv, ny * inv, nz * inv };
+            float lo[3], hi[3];
 
-          buf_store_f32x4_aux<MAPAUX>(make_float4(lo[0], lo[1], lo[2], 0.0f), rmaps, olo, T * s * 2 * N * 16);
-          buf_store_f32x4_aux<MAPAUX>(make_float4(hi[0], hi[1], hi[2], 0.0f), rmaps, ohi, T * s * 2 * N * 16);
-        }
-        else
-        {
-          buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * 2 * N * 16);
-          buf_store_f32x4_aux<MAPAUX>(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, T * s * 2 * N * 16 + MAP_GROUP * 16);
+            #pragma unroll
+            for(int k = 0; k < 3; ++k)
+            {
+              // row of the even quad: its own displacement | the normal of the even quad, fetched by the odd quad from four lanes down
+              lo[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, dsp[k]), __builtin_bit_cast(int, nrm[k]), 0x114, 0xF, 0xA, false));
+              // row of the odd quad: the displacement of the odd quad, fetched by the even quad from four lanes up | its own normal
+              hi[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, nrm[k]), __builtin_bit_cast(int, dsp[k]), 0x104, 0xF, 0x5, false));
+            }
+
+            buf_store_f32x4_aux<MAPAUX>(make_float4(lo[0], lo[1], lo[2], 0.0f), rmaps, olo, T * s * 2 * N * 16);
+            buf_store_f32x4_aux<MAPAUX>(make_float4(hi[0], hi[1], hi[2], 0.0f), rmaps, ohi, T * s * 2 * N * 16);
+          }
+          else
+          {
+            buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * 2 * N * 16);
+            buf_store_f32x4_aux<MAPAUX>(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, T * s * 2 * N * 16 + MAP_GROUP * 16);
+          }
         }
       }
-    }
 
-    OCEAN_STAMP(4);
+      OCEAN_STAMP(4);
+    };
+
+    int item = (int)blockIdx.x;
+
+    Raw q[E];
+
+    request(item, t_, cp_, q);
+
+    OCEAN_WAIT_LOADS();
+    OCEAN_STAMP(1);
+
+    if constexpr (!WALK)
+      one_tile(item, q, false, 0);
+    else
+    {
+      int const stride = (int)gridDim.x;
+
+      // first tile (peeled), then the rest
+      one_tile(item, q, item + stride < items, item + stride);
+
+      for(item += stride; item < items; item += stride)
+      {
+        // the heights of the previous tile were read from the LDS this tile's first pass writes
+        __syncthreads();
+
+#ifdef OCEAN_COL_NO_PREFETCH
+        request(item, t_, cp_, q);
+#endif
+
+        one_tile(item, q, item + stride < items, item + stride);
+      }
+    }
   }
 
   // blocked packed spectrum -> two row-major complex planes (datum_ocean_debug_rowpass)
@@ -958,7 +1141,7 @@ namespace ocean
     {
       int y = (int)(i / N), x = (int)(i % N);
 
-      size_t const at = ((size_t)((y >> 3) * (N / 8) + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7);
+      size_t const at = blocked_at(N, y, x);
 
       float4 v;
 
