@@ -506,9 +506,15 @@ int datum_ocean_maps_device(datum_ocean_t ctx, void **device_ptr, size_t *bytes)
   return DATUM_OCEAN_OK;
 }
 
-int datum_ocean_map_group(void)
+int datum_ocean_map_layout(int resolution, int *group, int *band)
 {
-  return MAP_GROUP;
+  if (!supported(resolution) || !group || !band)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_map_layout: bad argument");
+
+  *group = MAP_GROUP;
+  *band = band_cols(resolution);
+
+  return DATUM_OCEAN_OK;
 }
 
 int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, float choppiness)

@@ -182,8 +182,11 @@ namespace ocean
 
     float const w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
 
-    int const r0 = j0 * 2 * N, r1 = j1 * 2 * N;
-    int const c0 = (i0 / MAP_GROUP) * (2 * MAP_GROUP) + (i0 % MAP_GROUP), c1 = (i1 / MAP_GROUP) * (2 * MAP_GROUP) + (i1 % MAP_GROUP);
+    // map_index, rows and columns apart (large maps are stored in bands of columns)
+    int const B = band_cols(N);
+    int const r0 = j0 * 2 * B, r1 = j1 * 2 * B;
+    int const c0 = (i0 / B) * 2 * N * B + ((i0 % B) / MAP_GROUP) * (2 * MAP_GROUP) + (i0 % MAP_GROUP);
+    int const c1 = (i1 / B) * 2 * N * B + ((i1 % B) / MAP_GROUP) * (2 * MAP_GROUP) + (i1 % MAP_GROUP);
 
     bool const shaded = smoothing != 1.0f;       // otherwise the sampled normal is multiplied by an exact 0
 

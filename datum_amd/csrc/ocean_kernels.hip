@@ -90,10 +90,25 @@ namespace ocean
 #endif
   constexpr int SBR = OCEAN_SPEC_BLOCK_ROWS, SBC = OCEAN_SPEC_BLOCK_COLS;
 
-  // element index of grid point (y, x) in the blocked work spectrum: blocks of SBR rows x SBC columns, row-major inside
+  // Bands (large grids): the columns one XCD's column-pass workgroups work on at the same time are made contiguous in
+  // memory -- [x / B][rows][x % B] -- for the work spectrum and for the maps alike, so that what is read and written
+  // concurrently is a dense region instead of 2 KB pieces of rows 128 KB apart (4096^2).  B = band_cols(N), 0 = whole rows.
+  // measured (profiles/r02_large_grids.txt): 4096^2 B = 64 (32 CUs x 2-column tiles): column pass 240 -> 226 us, with the
+  // fp16-stored spectrum 202 -> 164 us; 2048^2 x 4 B = 128 (32 CUs x 4-column tiles): 181 -> 167 us; B = 512 at 4096^2: 270 us
+#ifndef OCEAN_BAND_COLS_4096
+#define OCEAN_BAND_COLS_4096 64
+#endif
+#ifndef OCEAN_BAND_COLS_2048
+#define OCEAN_BAND_COLS_2048 128
+#endif
+  __host__ __device__ __forceinline__ constexpr int band_cols(int N) { return (N >= 4096) ? OCEAN_BAND_COLS_4096 : (N >= 2048) ? OCEAN_BAND_COLS_2048 : N; }
+
+  // element index of grid point (y, x) in the blocked work spectrum: per band, blocks of SBR rows x SBC columns, row-major inside
   __host__ __device__ __forceinline__ constexpr size_t blocked_at(int N, int y, int x)
   {
-    return ((size_t)(y / SBR) * (N / SBC) + (x / SBC)) * (SBR * SBC) + (y % SBR) * SBC + (x % SBC);
+    int const B = band_cols(N);
+
+    return (size_t)(x / B) * N * B + ((size_t)(y / SBR) * (B / SBC) + (x % B) / SBC) * (SBR * SBC) + (y % SBR) * SBC + (x % SBC);
   }
 
   template<int N>
@@ -114,11 +129,16 @@ namespace ocean
 #endif
   constexpr int MAP_GROUP = OCEAN_MAP_GROUP;
 
-  // float4 index of texel (x, y) of `layer`:
+  // float4 index of texel (x, y) of `layer` (bands as for the spectrum: [x / B][y][groups of the band's row]):
   __host__ __device__ __forceinline__ constexpr size_t map_index(int N, int y, int x, int layer)
   {
-    return (size_t)y * 2 * N + (size_t)(x / MAP_GROUP) * (2 * MAP_GROUP) + layer * MAP_GROUP + (x % MAP_GROUP);
+    int const B = band_cols(N);
+
+    return (size_t)(x / B) * 2 * N * B + (size_t)y * 2 * B + (size_t)((x % B) / MAP_GROUP) * (2 * MAP_GROUP) + layer * MAP_GROUP + (x % MAP_GROUP);
   }
+
+  // float4 from one row of the maps to the next (same column)
+  __host__ __device__ __forceinline__ constexpr int map_row_pitch(int N) { return 2 * band_cols(N); }
 
   //|---------------------- buffer addressing ----------------------------------
   // Global accesses whose addresses differ between a thread's slots only by a wave-uniform amount go through
@@ -830,9 +850,9 @@ namespace ocean
 #define OCEAN_COL_WALK_FROM 2048
 #endif
 
-  // measured (profiles/r02_large_grids.txt): 2048^2 x 4 208 -> 187 us, 4096^2 with the fp16-stored spectrum 214 -> 196 us,
-  // 4096^2 fp32 248 -> 259 us (126 registers of the 128 a thread may have there): not walked
-  template<int N, bool H16> constexpr bool col_walks() { return N >= OCEAN_COL_WALK_FROM && (H16 || N < 4096); }
+  // measured (profiles/r02_large_grids.txt), with the band layouts: 2048^2 x 4 182 -> 168 us, 4096^2 219 -> 210 us; without
+  // them 208 -> 187 us and 248 -> 259 us (not every step of this was a gain on its own)
+  template<int N, bool H16> constexpr bool col_walks() { return N >= OCEAN_COL_WALK_FROM; }
 
   template<int N, bool H16>
   __global__ void __launch_bounds__(ColCfg<N>::THREADS, OCEAN_COL_MINBLOCKS) ocean_colpass_kernel(StepArgs a)
@@ -1085,13 +1105,13 @@ namespace ocean
               hi[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, nrm[k]), __builtin_bit_cast(int, dsp[k]), 0x104, 0xF, 0x5, false));
             }
 
-            buf_store_f32x4_aux<MAPAUX>(make_float4(lo[0], lo[1], lo[2], 0.0f), rmaps, olo, T * s * 2 * N * 16);
-            buf_store_f32x4_aux<MAPAUX>(make_float4(hi[0], hi[1], hi[2], 0.0f), rmaps, ohi, T * s * 2 * N * 16);
+            buf_store_f32x4_aux<MAPAUX>(make_float4(lo[0], lo[1], lo[2], 0.0f), rmaps, olo, T * s * map_row_pitch(N) * 16);
+            buf_store_f32x4_aux<MAPAUX>(make_float4(hi[0], hi[1], hi[2], 0.0f), rmaps, ohi, T * s * map_row_pitch(N) * 16);
           }
           else
           {
-            buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * 2 * N * 16);
-            buf_store_f32x4_aux<MAPAUX>(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, T * s * 2 * N * 16 + MAP_GROUP * 16);
+            buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * map_row_pitch(N) * 16);
+            buf_store_f32x4_aux<MAPAUX>(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, T * s * map_row_pitch(N) * 16 + MAP_GROUP * 16);
           }
         }
       }
@@ -1196,13 +1216,14 @@ namespace ocean
       size_t const row = g / (N / 4);                 // cascade * N + y
       int const x0 = (int)(g % (N / 4)) * 4;
 
-      float4 const *src = maps + row * 2 * N;         // map_index of (x, y = 0, layer 0) within this row
+      float4 const *src = maps + (row / N) * 2 * N * N;      // the cascade's map block
+      int const y = (int)(row % N);
 
       float4 t[4];
 
       #pragma unroll
       for(int k = 0; k < 4; ++k)
-        t[k] = src[map_index(N, 0, x0 + k, 0)];
+        t[k] = src[map_index(N, y, x0 + k, 0)];
 
       if constexpr (HALF)
       {

@@ -79,12 +79,13 @@ int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream, int use_own);
  * cascades * 2 * N * N * 4 floats (e.g. a buffer that is later all-gathered); NULL restores the
  * handle's own buffer.
  * DEVICE LAYOUT of a cascade's map block (the reference's displacementmap is a VK_IMAGE_TILING_OPTIMAL image,
- * ocean.cpp:706, whose physical layout is the driver's; its only reader is ocean.gen): per row y, per group g of
- * G = datum_ocean_map_group() texels, 4 G floats of layer 0 (texels G g .. G g + G - 1: dx, dy, dz, 0) followed by
- * 4 G floats of layer 1 (the same texels: nx, ny, nz, 0); float4 index of texel (x, y, layer) =
- * y * 2N + (x / G) * 2G + layer * G + x % G.  datum_ocean_read_maps returns the logical image [layer][y][x][4]. */
+ * ocean.cpp:706, whose physical layout is the driver's; its only reader is ocean.gen): bands of B columns (B = N
+ * except for the largest grids), per band row after row, per row groups of G texels: 4 G floats of layer 0 (texels
+ * G g .. G g + G - 1: dx, dy, dz, 0) followed by 4 G floats of layer 1 (the same texels: nx, ny, nz, 0).  float4 index of
+ * texel (x, y, layer) = (x / B) * 2 N B + y * 2 B + ((x % B) / G) * 2 G + layer * G + x % G, with (G, B) from
+ * datum_ocean_map_layout.  datum_ocean_read_maps returns the logical image [layer][y][x][4]. */
 int datum_ocean_bind_maps(datum_ocean_t ctx, void *device_ptr, size_t bytes);
-int datum_ocean_map_group(void);
+int datum_ocean_map_layout(int resolution, int *group, int *band);
 int datum_ocean_maps_device(datum_ocean_t ctx, void **device_ptr, size_t *bytes);
 
 /* -- state (OceanParams arrays, ocean.h:67-72) ------------------------------------------------------- */
