@@ -153,8 +153,11 @@ namespace
     void *args[] = { &a };
     void const *kernel = ctx->half ? reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, true>) : reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>);
 
-    // work items = groups of row pairs x cascades, one workgroup each
-    return launch(kernel, dim3(RowCfg<N>::GROUPS * ctx->cascades), dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream, ev);
+    // work items = groups of row pairs x cascades: one workgroup each, or (largest grids) one persistent workgroup per
+    // compute unit that walks its share
+    int const items = RowCfg<N>::GROUPS * ctx->cascades;
+
+    return launch(kernel, dim3(row_walks<N>() ? std::min(items, ctx->cus) : items), dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream, ev);
   }
 
   template<int N>

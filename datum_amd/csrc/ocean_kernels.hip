@@ -499,6 +499,10 @@ namespace ocean
   // is -pi N scale at both): the general form  F_H = (F[k] + conj(F[-k])) / 2  is evaluated with the sign that
   // applies, so the result equals the reference's three transforms to rounding (tests/test_oracle_pins.py).
 
+#ifndef OCEAN_ROW_WALK_FROM
+#define OCEAN_ROW_WALK_FROM 4096
+#endif
+
   template<int N>
   struct RowCfg
   {
@@ -513,7 +517,8 @@ namespace ocean
     static constexpr int PS = 4;
     static constexpr int LINE = LineFFT<N, PS>::LINE;
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
-    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)PAIRS * 2 * K * LINE) * sizeof(cf);
+    static constexpr bool WALK = (N >= OCEAN_ROW_WALK_FROM) && PAIRS == 1;       // see ocean_rowpass_kernel
+    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)4 * T : 0)) * sizeof(cf);      // + the walking variant's twiddle stash
 
     static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
   };
@@ -550,11 +555,18 @@ namespace ocean
     }
   }
 
-  // One group of row pairs per workgroup.  (Persistent workgroups that walk several pairs and request the next pair's
-  // inputs ahead -- what the column pass does from 2048^2 up -- were measured at 4096^2, where one 1024-thread workgroup
-  // fills a CU: the 48 registers of inputs in flight on top of the transforms' own exceed the 128 a thread may have there,
-  // hipcc spills, and a spill's reload waits for vmcnt(0), i.e. for the stores that should have drained meanwhile:
-  // 250 us against 181 us; walking without the prefetch: 180 us.  profiles/r02_large_grids.txt)
+  // One group of row pairs per workgroup -- except at N >= OCEAN_ROW_WALK_FROM, where one 1024-thread workgroup fills a CU
+  // (LDS) and a pair's phases ran one after the other with 4-5 us between two workgroups on a CU (store drain + launch):
+  // there the workgroups are persistent and walk their pairs; the next pair's inputs are requested behind the transforms,
+  // BEFORE the current pair's stores, so that the wait for them counts past those stores and the stores drain under the next
+  // pair's arithmetic (4096^2: 178 -> 168 us).  What it took to keep hipcc from spilling at the 128 registers a thread may
+  // have there (a spill's reload is a vector-memory load whose wait drains the very stores that should overlap): the request
+  // is unconditional (the last pair requests itself again: under "if (more)" the old inputs stay live as the other arm of
+  // the merge), the thread's twiddles wait in LDS between pairs, and its coordinates are re-derived per pair from an opaque
+  // copy of its index.  Requested earlier, before the transforms, the inputs' 48 registers do not fit (nor, two rows per
+  // thread in 512-thread workgroups, their 96 on top of 209 in 256): profiles/r02_large_grids.txt.
+  template<int N> constexpr bool row_walks() { return RowCfg<N>::WALK; }
+
   template<int N, bool H16>
   __global__ void __launch_bounds__(RowCfg<N>::THREADS) ocean_rowpass_kernel(StepArgs a)
   {
@@ -583,7 +595,7 @@ namespace ocean
     auto group_of = [&](int item) { int const q = item % G; return (G % 8 == 0) ? (q & 7) * (G / 8) + (q >> 3) : q; };
 
     int const pr = threadIdx.x / (2 * T);
-    int const half = (threadIdx.x % (2 * T)) / T;
+    int half = (threadIdx.x % (2 * T)) / T;           // (the walking variant re-derives it per item)
     int const t_ = threadIdx.x % T;
 
     size_t const plane = (size_t)N * N;
@@ -662,17 +674,56 @@ namespace ocean
     OCEAN_STAMP_WHERE();
     OCEAN_STAMP(0);
 
+    constexpr bool WALK = row_walks<N>();
+
+    static_assert(!WALK || 1 + LineTw<N>::type::NMIDREG + P::M <= 4, "twiddle stash");
+
+    cf *twstash = midtab + L::MIDTAB + C::PAIRS * 2 * K * C::LINE;       // [4][T], walking only
+
+    if constexpr (WALK)
     {
-      int const item = (int)blockIdx.x;
-      int const t = t_;
-      cf const ca = ca_;
-      typename LineTw<N>::type const &w = w_;
+      if (half == 0)
+      {
+        twstash[t_] = ca_;
 
-      Inputs in;
+        #pragma unroll
+        for(int k = 0; k < LineTw<N>::type::NMIDREG; ++k)
+          twstash[(1 + k) * T + t_] = w_.mid[k];
 
-      request(item, t, in);
+        #pragma unroll
+        for(int m = 0; m < P::M; ++m)
+          twstash[(1 + LineTw<N>::type::NMIDREG + m) * T + t_] = w_.last[m];
+      }
 
-      OCEAN_WAIT_LOADS();
+      __syncthreads();
+    }
+
+    auto one_item = [&](int item, Inputs &in, int next)
+    {
+      int t = t_;
+      cf ca = ca_;
+      typename LineTw<N>::type w = w_;
+
+      if constexpr (WALK)
+      {
+        int tid = (int)threadIdx.x;
+
+        asm volatile("" : "+v"(tid));
+
+        t = tid % T;
+        half = (tid % (2 * T)) / T;
+
+        ca = twstash[t];
+
+        #pragma unroll
+        for(int k = 0; k < LineTw<N>::type::NMIDREG; ++k)
+          w.mid[k] = twstash[(1 + k) * T + t];
+
+        #pragma unroll
+        for(int m = 0; m < P::M; ++m)
+          w.last[m] = twstash[(1 + LineTw<N>::type::NMIDREG + m) * T + t];
+      }
+
       OCEAN_STAMP(1);
 
       int const cascade = item / G;
@@ -779,6 +830,9 @@ namespace ocean
       fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
 #endif
 
+      if constexpr (WALK)
+        request(next, t, in);
+
       OCEAN_STAMP(4);
 
       #pragma unroll
@@ -799,6 +853,28 @@ namespace ocean
       }
 
       OCEAN_STAMP(5);
+    };
+
+    int item = (int)blockIdx.x;
+
+    Inputs in;
+
+    request(item, t_, in);
+
+    OCEAN_WAIT_LOADS();
+
+    if constexpr (!WALK)
+      one_item(item, in, item);
+    else
+    {
+      int const stride = (int)gridDim.x;
+      int const items = G * a.cascades;
+
+      // first item peeled: the counted wait at the top of the loop body needs one history on every path into it
+      one_item(item, in, item + stride < items ? item + stride : item);
+
+      for(item += stride; item < items; item += stride)
+        one_item(item, in, item + stride < items ? item + stride : item);
     }
   }
 
