@@ -40,11 +40,18 @@ emul: $(EMUL)
 $(EMUL): tests/cpu/fft_core_emul.cpp datum_amd/csrc/ocean_fft_core.h
 	$(CXX) -O2 -std=c++14 -fPIC -shared -o $@ tests/cpu/fft_core_emul.cpp
 
+# stand-in for the Vulkan side of the external-memory handshake (GPU tests only)
+EXTMEM = tests/gpu/libextmem_helper.so
+helpers: $(EXTMEM)
+
+$(EXTMEM): tests/gpu/extmem_helper.hip
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -o $@ tests/gpu/extmem_helper.hip
+
 resource-usage: $(SRC) $(DEPS)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(SRC) 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" 
 
 clean:
-	rm -f $(LIB) $(HOSTLIB) $(EMUL) $(EXAMPLE)
+	rm -f $(LIB) $(HOSTLIB) $(EMUL) $(EXAMPLE) $(EXTMEM)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle emul examples clean resource-usage
+.PHONY: all oracle emul helpers examples clean resource-usage

@@ -71,6 +71,12 @@ SYMBOLS = {
     "datum_ocean_sync": (I, [P]),
     "datum_ocean_wait_event": (I, [P, P]),
     "datum_ocean_signal": (I, [P, ctypes.POINTER(P)]),
+    "datum_ocean_import_memory_fd": (I, [P, I, ctypes.c_size_t, ctypes.POINTER(P)]),
+    "datum_ocean_release_memory": (I, [P, P]),
+    "datum_ocean_import_semaphore_fd": (I, [P, I, ctypes.POINTER(P)]),
+    "datum_ocean_release_semaphore": (I, [P, P]),
+    "datum_ocean_signal_external": (I, [P, P]),
+    "datum_ocean_wait_external": (I, [P, P]),
     "datum_ocean_device_alloc": (I, [P, ctypes.c_size_t, ctypes.POINTER(P)]),
     "datum_ocean_device_free": (I, [P, P]),
     "datum_ocean_device_write": (I, [P, P, P, ctypes.c_size_t]),
@@ -221,6 +227,20 @@ class Ocean:
     def pack_displacement(self, fmt, device_ptr, nbytes):
         """Enqueue the packing of every cascade's displacement into caller-owned device memory (all-gather payload)."""
         self._check(self.lib.datum_ocean_pack_displacement(self.h, fmt, P(device_ptr), nbytes))
+
+    def import_memory_fd(self, fd, nbytes):
+        """Device pointer over memory another API exported as a POSIX fd (Vulkan external memory, opaque fd)."""
+        p = P()
+        self._check(self.lib.datum_ocean_import_memory_fd(self.h, fd, nbytes, ctypes.byref(p)))
+        return p.value
+
+    def release_memory(self, device_ptr):
+        self._check(self.lib.datum_ocean_release_memory(self.h, P(device_ptr)))
+
+    def import_semaphore_fd(self, fd):
+        p = P()
+        self._check(self.lib.datum_ocean_import_semaphore_fd(self.h, fd, ctypes.byref(p)))
+        return p.value
 
     def read_maps(self, cascade):
         out = np.empty((2, self.N, self.N, 4), np.float32)

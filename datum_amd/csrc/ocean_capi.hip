@@ -41,8 +41,7 @@ struct datum_ocean_ctx
   float4 *ownmaps = nullptr;
   cf *tw = nullptr;
   float *omega = nullptr;             // [cascade][(N/2+1)^2] dispersion quadrant, rebuilt when a wavescale changes
-  float *wavescales = nullptr;        // [MAX_CASCADES] device copy for the table build
-  bool omegadirty = true;
+  unsigned int omegadirty = ~0u;      // cascades whose wave scale changed since their table was built
   float omegamax[DATUM_OCEAN_MAX_CASCADES] = {};   // largest dispersion of each cascade (table corner)
   bool wildphase[DATUM_OCEAN_MAX_CASCADES] = {};   // an uploaded phase lies outside [0, 2 pi)
   cf *scratch = nullptr;              // 3 row-major planes for the debug read-backs (lazy)
@@ -53,6 +52,11 @@ struct datum_ocean_ctx
   std::vector<float> pending;         // queued update_ocean dt's
 
   hipEvent_t complete = nullptr;      // "rendercomplete"
+
+  // imported from the renderer (Vulkan external memory / semaphores)
+  struct ImportedMemory { hipExternalMemory_t memory; void *ptr; size_t bytes; };
+  std::vector<ImportedMemory> importedmemory;
+  std::vector<hipExternalSemaphore_t> importedsemaphores;
 
   // profiling
   bool profiling = false;
@@ -189,30 +193,30 @@ namespace
       case 4096: { constexpr int NN = 4096; expr; } break; \
     }
 
-  // (re)build the dispersion quadrant tables after a wavescale change
+  // (re)build the dispersion quadrant tables of the cascades whose wave scale changed
   int ensure_omega(datum_ocean_ctx *ctx)
   {
-    if (!ctx->omegadirty)
+    unsigned int const dirty = ctx->omegadirty & ((ctx->cascades >= 32) ? ~0u : ((1u << ctx->cascades) - 1));
+
+    if (!dirty)
       return DATUM_OCEAN_OK;
 
-    float ws[DATUM_OCEAN_MAX_CASCADES];
+    WaveScales ws;
+
     for(int c = 0; c < DATUM_OCEAN_MAX_CASCADES; ++c)
     {
-      ws[c] = ctx->casc[c].wavescale;
+      ws.v[c] = ctx->casc[c].wavescale;
 
       // dispersion grows with |k|: its maximum is the table corner |m - N/2| = |n - N/2| = N/2 (same fp32 formula)
-      float kc = (6.2831855f * (0.5f * (float)ctx->N)) / ws[c];
+      float kc = (6.2831855f * (0.5f * (float)ctx->N)) / ws.v[c];
       float k2 = kc * kc + kc * kc;
       ctx->omegamax[c] = sqrtf((9.81f * sqrtf(k2)) * (1.0f + k2 / 136900.0f));
     }
 
-    HIPCHECK(ctx, hipMemcpyAsync(ctx->wavescales, ws, sizeof(ws), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));   // ws lives on this stack frame
-
-    hipLaunchKernelGGL(ocean_omega_kernel, dim3(512), dim3(256), 0, ctx->stream, ctx->omega, ctx->N, ctx->cascades, ctx->wavescales);
+    hipLaunchKernelGGL(ocean_omega_kernel, dim3(512), dim3(256), 0, ctx->stream, ctx->omega, ctx->N, ctx->cascades, ws, dirty);
     HIPCHECK(ctx, hipGetLastError());
 
-    ctx->omegadirty = false;
+    ctx->omegadirty = 0;
 
     return DATUM_OCEAN_OK;
   }
@@ -372,7 +376,6 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
   CREATECHECK(hipMalloc(&ctx->ownmaps, cascades * 2 * P * sizeof(float4)));
   CREATECHECK(hipMalloc(&ctx->tw, resolution * sizeof(cf)));
   CREATECHECK(hipMalloc(&ctx->omega, (size_t)cascades * (resolution / 2 + 1) * (resolution / 2 + 1) * sizeof(float)));
-  CREATECHECK(hipMalloc(&ctx->wavescales, DATUM_OCEAN_MAX_CASCADES * sizeof(float)));
   ctx->maps = ctx->ownmaps;
 
   CREATECHECK(hipMemsetAsync(ctx->h0, 0, cascades * P * sizeof(float2), ctx->stream));
@@ -443,6 +446,12 @@ int datum_ocean_destroy(datum_ocean_t ctx)
   if (ctx->complete)
     (void)hipEventDestroy(ctx->complete);
 
+  for(auto &im : ctx->importedmemory)
+    (void)hipDestroyExternalMemory(im.memory);
+
+  for(hipExternalSemaphore_t sem : ctx->importedsemaphores)
+    (void)hipDestroyExternalSemaphore(sem);
+
   (void)hipFree(ctx->h0);
   (void)hipFree(ctx->seed);
   (void)hipFree(ctx->phase);
@@ -451,7 +460,6 @@ int datum_ocean_destroy(datum_ocean_t ctx)
   (void)hipFree(ctx->ownmaps);
   (void)hipFree(ctx->tw);
   (void)hipFree(ctx->omega);
-  (void)hipFree(ctx->wavescales);
   (void)hipFree(ctx->scratch);
 
   if (ctx->ownstream)
@@ -543,7 +551,7 @@ int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, flo
   CascadeConst &cc = ctx->casc[cascade];
 
   if (cc.wavescale != wavescale)
-    ctx->omegadirty = true;
+    ctx->omegadirty |= 1u << cascade;
 
   cc.wavescale = wavescale;
   cc.scale = 1 / wavescale;                      // ocean.cpp:743
@@ -594,21 +602,24 @@ int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, fl
 
   HIPCHECK(ctx, hipMemcpyAsync(ctx->h0 + cascade * P, h0, P * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
 
-  bool wild = false;
+  unsigned int wild = 0;
 
   if (phase)
   {
-    for(size_t i = 0; i < P && !wild; ++i)
-      wild = !(phase[i] >= 0.0f && phase[i] < 6.2831855f);
-
     HIPCHECK(ctx, hipMemcpyAsync(ctx->phase + cascade * P, phase, P * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+
+    // phases outside [0, 2 pi) take the general fmod kernel: looked for on the device, where the array now is
+    HIPCHECK(ctx, hipMemsetAsync(ctx->absmax, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(ocean_phaserange_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->phase + cascade * P, P, ctx->absmax);
+    HIPCHECK(ctx, hipGetLastError());
+    HIPCHECK(ctx, hipMemcpyAsync(&wild, ctx->absmax, sizeof(wild), hipMemcpyDeviceToHost, ctx->stream));
   }
   else
     HIPCHECK(ctx, hipMemsetAsync(ctx->phase + cascade * P, 0, P * sizeof(float), ctx->stream));
 
-  ctx->wildphase[cascade] = wild;
-
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));   // the host buffers are the caller's again
+
+  ctx->wildphase[cascade] = wild != 0;
 
   ctx->uploaded[cascade] = true;
   ctx->scaledirty[cascade] = true;
@@ -938,6 +949,163 @@ int datum_ocean_signal(datum_ocean_t ctx, void **hip_event)
   HIPCHECK(ctx, hipEventRecord(ctx->complete, ctx->stream));
 
   *hip_event = ctx->complete;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_import_memory_fd(datum_ocean_t ctx, int fd, size_t bytes, void **device_ptr)
+{
+  if (!ctx || !device_ptr)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_import_memory_fd: null argument");
+
+  *device_ptr = nullptr;
+
+  if (fd < 0 || bytes == 0)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_import_memory_fd: bad descriptor or size");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  hipExternalMemoryHandleDesc desc = {};
+  desc.type = hipExternalMemoryHandleTypeOpaqueFd;       // VK_EXTERNAL_MEMORY_HANDLE_TYPE_OPAQUE_FD_BIT
+  desc.handle.fd = fd;
+  desc.size = bytes;
+
+  hipExternalMemory_t memory = nullptr;
+
+  HIPCHECK(ctx, hipImportExternalMemory(&memory, &desc));
+
+  hipExternalMemoryBufferDesc buffer = {};
+  buffer.offset = 0;
+  buffer.size = bytes;
+
+  void *ptr = nullptr;
+
+  hipError_t e = hipExternalMemoryGetMappedBuffer(&ptr, memory, &buffer);
+
+  if (e != hipSuccess || !ptr)
+  {
+    (void)hipDestroyExternalMemory(memory);
+    return fail(ctx, e != hipSuccess ? (int)e : DATUM_OCEAN_ENOMEM, "hipExternalMemoryGetMappedBuffer");
+  }
+
+  ctx->importedmemory.push_back({ memory, ptr, bytes });
+
+  *device_ptr = ptr;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_release_memory(datum_ocean_t ctx, void *device_ptr)
+{
+  if (!ctx || !device_ptr)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_release_memory: null argument");
+
+  for(size_t i = 0; i < ctx->importedmemory.size(); ++i)
+  {
+    if (ctx->importedmemory[i].ptr == device_ptr)
+    {
+      HIPCHECK(ctx, hipSetDevice(ctx->device));
+      HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));    // nothing enqueued may still write it
+
+      if (ctx->maps == device_ptr)
+        ctx->maps = ctx->ownmaps;
+
+      hipError_t e = hipDestroyExternalMemory(ctx->importedmemory[i].memory);
+
+      ctx->importedmemory.erase(ctx->importedmemory.begin() + i);
+
+      if (e != hipSuccess)
+        return fail(ctx, (int)e, "hipDestroyExternalMemory");
+
+      return DATUM_OCEAN_OK;
+    }
+  }
+
+  return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_release_memory: not a pointer this handle imported");
+}
+
+int datum_ocean_import_semaphore_fd(datum_ocean_t ctx, int fd, void **semaphore)
+{
+  if (!ctx || !semaphore)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_import_semaphore_fd: null argument");
+
+  *semaphore = nullptr;
+
+  if (fd < 0)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_import_semaphore_fd: bad descriptor");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  hipExternalSemaphoreHandleDesc desc = {};
+  desc.type = hipExternalSemaphoreHandleTypeOpaqueFd;    // VK_EXTERNAL_SEMAPHORE_HANDLE_TYPE_OPAQUE_FD_BIT
+  desc.handle.fd = fd;
+
+  hipExternalSemaphore_t sem = nullptr;
+
+  HIPCHECK(ctx, hipImportExternalSemaphore(&sem, &desc));
+
+  ctx->importedsemaphores.push_back(sem);
+
+  *semaphore = sem;
+
+  return DATUM_OCEAN_OK;
+}
+
+namespace
+{
+  bool owns_semaphore(datum_ocean_ctx *ctx, void *semaphore)
+  {
+    for(hipExternalSemaphore_t s : ctx->importedsemaphores)
+      if (s == semaphore)
+        return true;
+
+    return false;
+  }
+}
+
+int datum_ocean_release_semaphore(datum_ocean_t ctx, void *semaphore)
+{
+  if (!ctx || !semaphore || !owns_semaphore(ctx, semaphore))
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_release_semaphore: not a semaphore this handle imported");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+  for(size_t i = 0; i < ctx->importedsemaphores.size(); ++i)
+    if (ctx->importedsemaphores[i] == semaphore)
+      ctx->importedsemaphores.erase(ctx->importedsemaphores.begin() + i--);
+
+  HIPCHECK(ctx, hipDestroyExternalSemaphore((hipExternalSemaphore_t)semaphore));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_signal_external(datum_ocean_t ctx, void *semaphore)
+{
+  if (!ctx || !semaphore || !owns_semaphore(ctx, semaphore))
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_signal_external: not a semaphore this handle imported");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  hipExternalSemaphore_t sem = (hipExternalSemaphore_t)semaphore;
+  hipExternalSemaphoreSignalParams params = {};
+
+  HIPCHECK(ctx, hipSignalExternalSemaphoresAsync(&sem, &params, 1, ctx->stream));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_wait_external(datum_ocean_t ctx, void *semaphore)
+{
+  if (!ctx || !semaphore || !owns_semaphore(ctx, semaphore))
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_wait_external: not a semaphore this handle imported");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  hipExternalSemaphore_t sem = (hipExternalSemaphore_t)semaphore;
+  hipExternalSemaphoreWaitParams params = {};
+
+  HIPCHECK(ctx, hipWaitExternalSemaphoresAsync(&sem, &params, 1, ctx->stream));
 
   return DATUM_OCEAN_OK;
 }

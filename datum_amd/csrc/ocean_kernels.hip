@@ -230,13 +230,20 @@ namespace ocean
   // wavescale with the formula above, serves every step: omega[i * (N/2+1) + j] = dispersion at |m - N/2| = i,
   // |n - N/2| = j.  The row pass then pays one L2-resident load instead of two IEEE divides and two IEEE
   // square roots per point, and the phase it produces is still bit-identical to update_ocean's.
-  __global__ void ocean_omega_kernel(float *omega, int N, int cascades, float const *wavescales)
+  struct WaveScales { float v[DATUM_OCEAN_MAX_CASCADES]; };
+
+  // (the wave scales travel by value in the kernel arguments and only the cascades in `dirty` are rebuilt: a blend of
+  // the wave parameters changes one cascade's scale every frame, lerp_ocean_waves, ocean.cpp:185-192)
+  __global__ void ocean_omega_kernel(float *omega, int N, int cascades, WaveScales wavescales, unsigned int dirty)
   {
     int const Q = N / 2 + 1;
 
     for(int cascade = 0; cascade < cascades; ++cascade)
     {
-      float const wavescale = wavescales[cascade];
+      if (!((dirty >> cascade) & 1))
+        continue;
+
+      float const wavescale = wavescales.v[cascade];
       float *table = omega + (size_t)cascade * Q * Q;
 
       for(size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < (size_t)Q * Q; k += (size_t)gridDim.x * blockDim.x)
@@ -246,6 +253,22 @@ namespace ocean
         table[k] = dispersion_at(N / 2 + j, N / 2 + i, N, wavescale);
       }
     }
+  }
+
+  // does an uploaded phase array leave [0, 2 pi)?  (the fused row pass's one-subtraction fmod is exact only inside)
+  __global__ void ocean_phaserange_kernel(float const *phase, size_t count, unsigned int *wild)
+  {
+    bool bad = false;
+
+    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    {
+      float const p = phase[i];
+
+      bad |= !(p >= 0.0f && p < 6.2831855f);
+    }
+
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0)
+      atomicOr(wild, 1u);
   }
 
   __device__ __forceinline__ float dispersion_lookup(float const *table, int n, int m, int N)

@@ -69,6 +69,7 @@ extern "C"
 
   void *datum_host_params_create(int resolution) { return new OceanParams(resolution); }
   void datum_host_params_destroy(void *p) { delete static_cast<OceanParams*>(p); }
+  void *datum_host_params_clone(void *p) { return new OceanParams(*static_cast<OceanParams*>(p)); }       // OceanParams is copyable, like the reference's POD
 
   void datum_host_params_get(void *p, datum_host_scalars *s)
   {
@@ -84,7 +85,7 @@ extern "C"
     s->flow[0] = o.flow.x; s->flow[1] = o.flow.y;
     s->resolution = o.resolution;
     s->rejectedseeds = o.rejectedseeds;
-    s->pending = (int)o.pending.size();
+    s->pending = (int)o.updates.size();      // recorded update_ocean calls (OceanParams::updates)
   }
 
   // tunables only; state (swellphase, flow, arrays) is left alone

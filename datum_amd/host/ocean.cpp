@@ -129,25 +129,53 @@ namespace
     rebuild_height(params);
 
     params.flow = Vec2(0);
-    params.pending.clear();
+    params.updates.clear();
+    params.firstupdate = 0;
+    params.phaseupdates = 0;
     params.stateid = g_stateids++;
   }
 
-  // make the device hold this params' state: h0 (and phase when the whole state was replaced)
+  // make the device hold this params' state: h0 (and phase when the whole state was replaced), then every update_ocean
+  // step of the state's history that this context has not applied yet, each under the wavescale it was issued with
   void bind_state(OceanContext &context, OceanParams const &params)
   {
     assert(params.resolution == context.resolution);
 
-    check(context.hip, datum_ocean_set_cascade(context.hip, 0, params.wavescale, params.choppiness), "datum_ocean_set_cascade");
-
     if (context.boundstate != params.stateid)
     {
+      // params.phase is the state as of seed_ocean / the last fetch_ocean_state: the recorded history from there on comes on top
+      if (params.phaseupdates < params.firstupdate)
+        throw runtime_error("ocean: the update history behind OceanParams::phase is no longer recorded (fetch_ocean_state at least every OceanParams::MaxRecordedUpdates update_ocean calls before moving a state to another context)");
+
+      check(context.hip, datum_ocean_set_cascade(context.hip, 0, params.wavescale, params.choppiness), "datum_ocean_set_cascade");
       check(context.hip, datum_ocean_upload_state(context.hip, 0, params.height.data(), params.phase.data()), "datum_ocean_upload_state");
 
       context.boundstate = params.stateid;
       context.boundheight = params.heightid;
+      context.appliedupdates = params.phaseupdates;
     }
-    else if (context.boundheight != params.heightid && params.deviceheight)
+
+    uint64_t const last = params.firstupdate + params.updates.size();
+
+    if (context.appliedupdates < params.firstupdate)
+      throw runtime_error("ocean: more than OceanParams::MaxRecordedUpdates update_ocean calls since this context last rendered the state");
+
+    // the steps issued before a lerp_ocean_waves advanced the phase with the dispersion of the OLD wave scale
+    // (ocean.cpp:225-231 uses params.wavescale as it is at the call): replay each step under its own
+    for(uint64_t i = context.appliedupdates; i < last; ++i)
+    {
+      OceanParams::Update const &u = params.updates[i - params.firstupdate];
+
+      check(context.hip, datum_ocean_set_cascade(context.hip, 0, u.wavescale, params.choppiness), "datum_ocean_set_cascade");
+      check(context.hip, datum_ocean_update(context.hip, u.dt), "datum_ocean_update");
+    }
+
+    context.appliedupdates = max(context.appliedupdates, last);
+
+    // (a change of wave scale applies the updates queued on the device under the old one first: datum_ocean_set_cascade)
+    check(context.hip, datum_ocean_set_cascade(context.hip, 0, params.wavescale, params.choppiness), "datum_ocean_set_cascade");
+
+    if (context.boundheight != params.heightid && params.deviceheight)
     {
       // lerp_ocean_waves changed the wave parameters: rebuild h0 on the device from the resident seed
       if (context.boundseed != params.stateid)
@@ -171,11 +199,6 @@ namespace
 
       context.boundheight = params.heightid;
     }
-
-    for(float dt : params.pending)
-      check(context.hip, datum_ocean_update(context.hip, dt), "datum_ocean_update");
-
-    params.pending.clear();
   }
 }
 
@@ -241,7 +264,8 @@ OceanParams::OceanParams(int resolution)
   : resolution(resolution),
     seed((size_t)resolution * resolution * 2, 0.0f),
     height((size_t)resolution * resolution * 2, 0.0f),
-    phase((size_t)resolution * resolution, 0.0f)
+    phase((size_t)resolution * resolution, 0.0f),
+    stateid(g_stateids++)
 {
 }
 
@@ -311,8 +335,17 @@ void update_ocean(OceanParams &params, float dt)
 {
   params.swellphase = fmod(params.swellphase + (params.swellspeed * 2*pi<float>()/params.swelllength)*dt, 2*pi<float>());
 
-  // phase[m][n] = fmod(phase[m][n] + dispersion(k)*dt, 2 pi) is done by the row-pass kernel, in queue order
-  params.pending.push_back(dt);
+  // phase[m][n] = fmod(phase[m][n] + dispersion(k)*dt, 2 pi) is done by the row-pass kernel, in history order, with the
+  // dispersion of the wave scale in force now
+  params.updates.push_back(OceanParams::Update{ dt, params.wavescale });
+
+  if (params.updates.size() > OceanParams::MaxRecordedUpdates)
+  {
+    size_t const drop = params.updates.size() - OceanParams::MaxRecordedUpdates / 2;
+
+    params.updates.erase(params.updates.begin(), params.updates.begin() + drop);
+    params.firstupdate += drop;
+  }
 
   params.flow += params.windspeed * params.winddirection * dt;
 }
@@ -529,6 +562,11 @@ void fetch_ocean_state(OceanContext &context, OceanParams &params)
   bind_state(context, params);
 
   check(context.hip, datum_ocean_read_state(context.hip, 0, params.phase.data()), "datum_ocean_read_state");
+
+  // the host phase now contains the whole history: none of it needs to be kept for a later upload of these params
+  params.phaseupdates = params.firstupdate + params.updates.size();
+  params.firstupdate = params.phaseupdates;
+  params.updates.clear();
 
   if (params.deviceheight)
     check(context.hip, datum_ocean_read_height(context.hip, 0, params.height.data()), "datum_ocean_read_height");

@@ -140,9 +140,10 @@ struct OceanContext
 
   void *rendercomplete = nullptr;         // hipEvent_t recorded behind the last render (ocean.h:45)
 
-  std::uint64_t boundstate = 0;           // which OceanParams state is resident on the device
+  std::uint64_t boundstate = 0;           // which OceanParams state is resident on the device (0: none; state ids start at 1)
   std::uint64_t boundheight = 0;
   std::uint64_t boundseed = 0;            // which OceanParams seed is resident on the device (deviceheight only)
+  std::uint64_t appliedupdates = 0;       // how many of that state's update_ocean calls the device has applied (OceanParams::updates)
 
   OceanContext() = default;
   OceanContext(OceanContext const &) = delete;
@@ -183,9 +184,23 @@ struct OceanParams
   bool deviceheight = false;
 
   // device residency bookkeeping (not in the reference)
-  std::uint64_t stateid = 0;            // changes when seed_ocean replaces the whole state
+  //
+  // update_ocean's phase loop runs on the device, so update_ocean() only RECORDS the step: entry number
+  // `firstupdate + i` of this state's history is updates[i] = (dt, the wavescale in force at that call).  The history
+  // belongs to the state (stateid), not to one OceanParams object: OceanParams stays freely copyable like the reference's
+  // POD -- a per-frame copy handed to the render thread carries the same stateid and a prefix-consistent history -- and
+  // rendering is const: render_ocean_surface applies the entries the CONTEXT has not applied yet
+  // (OceanContext::appliedupdates) and never touches the params.  The history keeps the last MaxRecordedUpdates entries;
+  // a context that falls further behind than that throws.
+  struct Update { float dt, wavescale; };
+
+  static const std::size_t MaxRecordedUpdates = 4096;
+
+  std::uint64_t stateid;                // a fresh id per constructed / seeded state (never 0)
   std::uint64_t heightid = 0;           // changes when `height` is recomputed (lerp_ocean_waves)
-  mutable std::vector<float> pending;   // update_ocean dt's not yet applied on the device
+  std::uint64_t firstupdate = 0;        // history number of updates[0]
+  std::vector<Update> updates;          // update_ocean calls since firstupdate
+  std::uint64_t phaseupdates = 0;       // how many entries of the history `phase` (on the host) already contains
   int rejectedseeds = 0;                // seed pairs whose 8 polar draws were all rejected (see seed_ocean)
 
   explicit OceanParams(int resolution = OceanContext::WaveResolution);

@@ -61,6 +61,7 @@ def load():
             "datum_host_last_error": (ctypes.c_char_p, []),
             "datum_host_params_create": (P, [I]),
             "datum_host_params_destroy": (None, [P]),
+            "datum_host_params_clone": (P, [P]),
             "datum_host_params_get": (None, [P, ctypes.POINTER(Scalars)]),
             "datum_host_params_set": (None, [P, ctypes.POINTER(Scalars)]),
             "datum_host_params_set_deviceheight": (None, [P, I]),
@@ -108,6 +109,13 @@ class OceanParams:
         if getattr(self, "p", None):
             self.lib.datum_host_params_destroy(self.p)
             self.p = None
+
+    def copy(self):
+        """A C++ copy of the OceanParams (the reference's is a POD that game code copies freely)."""
+        c = OceanParams.__new__(OceanParams)
+        c.lib, c.N = self.lib, self.N
+        c.p = self.lib.datum_host_params_clone(self.p)
+        return c
 
     def scalars(self):
         s = Scalars()

@@ -158,6 +158,26 @@ int datum_ocean_sync(datum_ocean_t ctx);
 int datum_ocean_wait_event(datum_ocean_t ctx, void *hip_event);
 int datum_ocean_signal(datum_ocean_t ctx, void **hip_event);
 
+/* -- Vulkan <-> HIP interop, the HIP half --------------------------------------------------
+ * In datum the Ocean mesh's vertex buffer is a VkBuffer the graphics queue draws from (ocean.cpp:270, bound at
+ * geometrylist.cpp:463,513) and the frame's submit waits on the ocean's `rendercomplete` VkSemaphore (ocean.cpp:803,
+ * renderer.cpp:6848).  For the renderer to consume what this module writes without a copy, the renderer exports the
+ * buffer's VkDeviceMemory and its semaphores as POSIX file descriptors (VK_KHR_external_memory_fd /
+ * VK_KHR_external_semaphore_fd, handle type OPAQUE_FD) and this module imports them:
+ *   import_memory_fd     hipImportExternalMemory + hipExternalMemoryGetMappedBuffer: a device pointer over the same
+ *                        memory, valid for datum_ocean_gen (vertices) and datum_ocean_bind_maps.  On success the
+ *                        descriptor belongs to the handle (do not close it); released by release_memory or destroy.
+ *   import_semaphore_fd  hipImportExternalSemaphore; signal_external / wait_external enqueue a signal / a wait on the
+ *                        handle's stream: the rendercomplete semaphore and the up to 8 wait dependencies of the
+ *                        reference's submit (vulkan.cpp:1308-1328).
+ * INTEGRATION.md has the Vulkan side of the handshake. */
+int datum_ocean_import_memory_fd(datum_ocean_t ctx, int fd, size_t bytes, void **device_ptr);
+int datum_ocean_release_memory(datum_ocean_t ctx, void *device_ptr);
+int datum_ocean_import_semaphore_fd(datum_ocean_t ctx, int fd, void **semaphore);
+int datum_ocean_release_semaphore(datum_ocean_t ctx, void *semaphore);
+int datum_ocean_signal_external(datum_ocean_t ctx, void *semaphore);
+int datum_ocean_wait_external(datum_ocean_t ctx, void *semaphore);
+
 /* Device memory for the Ocean mesh (vertex buffer with compute-writable usage + index buffer,
  * ResourceManager::create<Ocean>, ocean.cpp:262-288) for hosts that do not link HIP themselves.
  * write/read are ordered on the handle's stream; read blocks until the data is on the host. */

@@ -21,12 +21,13 @@ def _ensure_built():
         os.path.join(ROOT, "datum_amd", "lib", "libdatum_ocean_host.so"),
         os.path.join(ROOT, "oracle", "liboracle.so"),
         os.path.join(ROOT, "tests", "cpu", "libfft_core_emul.so"),
+        os.path.join(ROOT, "tests", "gpu", "libextmem_helper.so"),
     ]
     if all(os.path.exists(p) for p in need):
         return
     env = dict(os.environ)
     env["PATH"] = "/opt/rocm/bin:" + env.get("PATH", "")
-    subprocess.check_call(["make", "-C", ROOT, "all", "emul"], env=env, stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", ROOT, "all", "emul", "helpers"], env=env, stdout=subprocess.DEVNULL)
 
 
 _ensure_built()

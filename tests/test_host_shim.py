@@ -97,7 +97,7 @@ def test_update_ocean_scalars_and_queue(host, oracle):
     s = p.scalars()
     assert s.swellphase == np.float32(sp)
     assert tuple(s.flow) == tuple(np.float32(v) for v in fl)
-    assert s.pending == 50  # the phase advance itself waits for the device
+    assert s.pending == 50  # the phase advance itself waits for the device: 50 recorded steps
     assert np.all(p.phase == 0)
 
 
