@@ -71,21 +71,35 @@ def measured_traffic(kernel, workload):
     return None, None
 
 
-def lavapipe_probe():
-    """north_star asks for the reference's shaders on the lavapipe software-Vulkan driver as the CPU baseline.  That
-    needs a Vulkan loader, the lvp ICD, a GLSL compiler and the reference's shader sources on the box; the sources do
-    not travel (no /root/reference there) and the rest is probed here so that the JSON line says what was found."""
+def lavapipe_probe(N):
+    """north_star asks for the reference's shaders on the lavapipe software-Vulkan driver as the CPU baseline.  The
+    reference's own shader files do not travel (no /root/reference on the GPU box) and only support N = 64;
+    tools/lavapipe/ holds this repository's N-generalised restatement of them plus a C harness.  It needs the Vulkan
+    headers + loader, the lvp ICD and glslangValidator: probed here; where everything exists the harness is built and
+    run (N <= 1024: one invocation per point of a line) and its line is returned, otherwise what is missing."""
     import ctypes.util
     import glob
     import shutil
+    import subprocess
 
     loader = ctypes.util.find_library("vulkan")
     icd = sorted(glob.glob("/usr/share/vulkan/icd.d/lvp_icd*.json") + glob.glob("/etc/vulkan/icd.d/lvp_icd*.json"))
-    glsl = shutil.which("glslangValidator") or shutil.which("glslc")
-    if loader and icd and glsl:
-        return f"loader {loader}, ICD {icd[0]}, {glsl} present, but the reference's shader sources are not on this box"
-    missing = [n for n, v in (("libvulkan", loader), ("lvp ICD", icd), ("glslangValidator/glslc", glsl)) if not v]
-    return "unavailable: no " + ", no ".join(missing)
+    glsl = shutil.which("glslangValidator")
+    header = os.path.exists("/usr/include/vulkan/vulkan.h")
+    missing = [n for n, v in (("libvulkan", loader), ("vulkan headers", header), ("lvp ICD", icd), ("glslangValidator", glsl)) if not v]
+    if missing:
+        return "unavailable: no " + ", no ".join(missing)
+    if N > 1024:
+        return "available, but the harness runs N <= 1024"
+    d = os.path.join(ROOT, "tools", "lavapipe")
+    try:
+        subprocess.run(["make", "-C", d, f"N={N}"], check=True, capture_output=True, timeout=120)
+        subprocess.run([sys.executable, os.path.join(d, "make_state.py"), str(N)], check=True, capture_output=True, timeout=120)
+        out = subprocess.run([os.path.join(d, "harness"), str(N), "50"], cwd=d, env=dict(os.environ, VK_ICD_FILENAMES=icd[0]),
+                             capture_output=True, text=True, timeout=300)
+        return "this repository's N-generalised restatement of the reference shaders (tools/lavapipe): " + out.stdout.strip().replace("\n", " | ")
+    except Exception as e:  # noqa: BLE001
+        return f"toolchain present but the harness failed: {e}"
 
 
 def cpu_baseline(N, cascades, states, budget):
@@ -109,7 +123,7 @@ def cpu_baseline(N, cascades, states, budget):
         el = time.perf_counter() - t0
         if el >= budget or grids >= 64 * cascades:
             break
-    return dict(value=grids / el, unit="grids/s", cores=oracle.num_threads(), kind="port", lavapipe=lavapipe_probe(),
+    return dict(value=grids / el, unit="grids/s", cores=oracle.num_threads(), kind="port", lavapipe=lavapipe_probe(N),
                 sample=f"{grids} grids = {grids // cascades} steps of {N}x{N} x {cascades} cascades in {el:.1f} s, "
                        f"oracle/ocean_oracle.cpp with OpenMP over rows/columns")
 
