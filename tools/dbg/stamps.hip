@@ -36,8 +36,8 @@ int main() {
   CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS));
   CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS));
   for (int it = 0; it < 5; ++it) {
-    hipLaunchKernelGGL((ocean_rowpass_kernel<N, false>), dim3(RowCfg<N>::GROUPS, C), dim3(RowCfg<N>::THREADS), RowCfg<N>::LDS, 0, a);
-    hipLaunchKernelGGL((ocean_colpass_kernel<N, false>), dim3(ColCfg<N>::TILES, C), dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, 0, a);
+    hipLaunchKernelGGL((ocean_rowpass_kernel<N, false>), dim3(row_walks<N>() ? 256 : RowCfg<N>::GROUPS * C), dim3(RowCfg<N>::THREADS), RowCfg<N>::LDS, 0, a);
+    hipLaunchKernelGGL((ocean_colpass_kernel<N, false>), dim3(col_walks<N, false>() ? 256 : ColCfg<N>::TILES * C), dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, 0, a);
   }
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> st(nst); CK(hipMemcpy(st.data(), stamps, nst*8, hipMemcpyDeviceToHost));
@@ -71,7 +71,7 @@ int main() {
     for (auto &kv : bycu) { if (shown++ >= 2) break; printf("   CU %06x:", kv.first); auto v = kv.second; std::sort(v.begin(), v.end(), [&](int x, int y){ return st[(base+x)*16] < st[(base+y)*16]; });
       for (int b : v) { auto *s = &st[(base + b) * 16]; printf("  [wg %d:", b); for (int k = 0; k <= nph; ++k) printf(" %.1f", (s[k] - t0) * 0.01); printf("]"); } printf("\n"); }
   };
-  analyse("rowpass", 0, RowCfg<N>::GROUPS * C, 5, {"start -> inputs arrived", "advance + phase stores + sim + swap barrier", "build C, D + barrier", "2-field transform (6 barriers)", "spectrum stores issued"});
-  analyse("colpass", 65536, ColCfg<N>::TILES * C, 4, {"start -> inputs arrived", "2-field transform (6 barriers)", "height exchange + barrier", "normals + map stores issued"});
+  analyse("rowpass", 0, row_walks<N>() ? 256 : RowCfg<N>::GROUPS * C, 5, {"start -> inputs arrived", "advance + phase stores + sim + swap barrier", "build C, D + barrier", "2-field transform (6 barriers)", "spectrum stores issued"});
+  analyse("colpass", 65536, col_walks<N, false>() ? 256 : ColCfg<N>::TILES * C, 4, {"start -> inputs arrived", "2-field transform (6 barriers)", "height exchange + barrier", "normals + map stores issued"});
   return 0;
 }
