@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--spectrum", choices=("fp32", "fp16"), default="fp32",
                     help="storage of the work spectrum between the two passes (fp16: BASELINE.json configs[4]; arithmetic stays fp32)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
+    ap.add_argument("--no-frame", action="store_true", help="skip the 64 x 64 reference-frame timing")
     ap.add_argument("--no-check", action="store_true", help="skip the output sanity check (timing-only ablation builds)")
     return ap.parse_args()
 
@@ -263,7 +264,42 @@ def main():
         gms = g0.elapsed_time(g1) / 20
         gbytes = 48.0 * sx * sy + 32.0 * N * N
         gen = {"mesh": f"{sx}x{sy}", "ms": gms, "vertices_per_s": sx * sy / (gms * 1e-3), "GBps": gbytes / (gms * 1e-3) / 1e9,
-               "bytes": gbytes, "finite": bool(torch.isfinite(verts).all())}
+               "bytes": gbytes, "frac_of_peak": gbytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, "finite": bool(torch.isfinite(verts).all())}
+
+    # the reference's own frame: WaveResolution = 64, one cascade, update_ocean + the five dispatches with a
+    # 1024 x 1024 mesh (examples/ocean/ocean.cpp:59,135,179) -- launch- and latency-bound, reported beside the headline
+    frame = None
+    if rank == 0 and not args.no_frame:
+        p64 = host_api.OceanParams(64, **host_api.EXAMPLE_TUNABLES)
+        p64.seed_ocean(1000)
+        with capi.Ocean(64, 1, device=local_rank) as o64:
+            o64.set_stream(stream.cuda_stream)
+            o64.set_cascade(0, host_api.EXAMPLE_TUNABLES["wavescale"], 1.35)
+            o64.upload_state(0, p64.height)
+            set64 = p64.oceanset()
+            f0, f1, f2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+
+            def frame64():
+                o64.update(DT)
+                o64.displace()
+                o64.gen(0, set64, sx, sy, verts.data_ptr())
+
+            for _ in range(20):
+                frame64()
+            f0.record(stream)
+            for _ in range(200):
+                frame64()
+            f1.record(stream)
+            for _ in range(200):
+                o64.update(DT)
+                o64.displace()
+            f2.record(stream)
+            torch.cuda.synchronize(dev)
+            frame = {"what": "update_ocean + sim/fftx/ffty/map at WaveResolution 64 + gen of a 1024x1024 mesh (the reference's shipped workload), back to back",
+                     "us_per_frame": f0.elapsed_time(f1) / 200 * 1e3, "us_displace_only": f1.elapsed_time(f2) / 200 * 1e3,
+                     "frames_per_s": 200 / (f0.elapsed_time(f1) * 1e-3)}
+            o64.set_stream(None)
+        del p64
     compute_ms = ev0.elapsed_time(ev1)     # the compute stream's share (serial: includes the gather it waits for)
     gather_ms = tg.last_collective_ms(slot) if gathering else 0.0
 
@@ -334,6 +370,7 @@ def main():
             "compute_ms": compute_ms,
             "gather_ms": gather_ms,
             "gen": gen,
+            "reference_frame_n64": frame,
             "value_compute_only": grids / (compute_ms * 1e-3) if (compute_ms > 0 and args.gather != "serial") else None,
         }
 
