@@ -59,14 +59,25 @@ def parse():
     return ap.parse_args()
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources: a committed PMC measurement is only quoted for the build it was made on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("ocean_kernels.hip", "ocean_fft_core.h", "ocean_gen.hip", "ocean_capi.hip"):
+        with open(os.path.join(ROOT, "datum_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/):
     bench.py cannot run the profiler on itself, so the value is the latest committed measurement for exactly this
-    kernel and workload, or None."""
+    kernel, workload AND kernel source (hash recorded by tools/profile_gpu.sh), or None when any of them differs."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if j.get("workload") == workload and kernel in j["kernels"]:
-            return j["kernels"][kernel]["traffic_bytes"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB)"
+        j = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        if j.get("workload") == workload and kernel in j["kernels"] and j.get("kernel_source_sha256_16") == kernel_source_hash():
+            return j["kernels"][kernel]["traffic_bytes"], "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB; same kernel sources)"
     except Exception:
         pass
     return None, None
@@ -316,6 +327,10 @@ def main():
 
         grids = args.steps * C * world
         row_b, col_b = oc.algorithmic_bytes()
+        # what the two kernels move by design: two packed fields instead of three -- 32 + 48 B/pt in fp32,
+        # 24 + 40 with the fp16-stored spectrum -- against the 40 + 56 (24 + 44) algorithmic bytes `achieved` is computed from
+        pts = float(N) * N * C
+        moved = ((24.0 if args.spectrum == "fp16" else 32.0) * pts, (40.0 if args.spectrum == "fp16" else 48.0) * pts)
         dom = ("colpass", col_ms, col_b) if col_ms >= row_ms else ("rowpass", row_ms, row_b)
         ach = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
         step_ach = (row_b + col_b) / ((row_ms + col_ms) * 1e-3) / 1e9 if row_ms + col_ms > 0 else 0.0
@@ -359,6 +374,10 @@ def main():
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
+                "hbm_bytes_by_design": {"rowpass": moved[0], "colpass": moved[1]},
+                "frac_of_peak_on_bytes_moved": {"rowpass": moved[0] / (row_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if row_ms > 0 else None,
+                                                "colpass": moved[1] / (col_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if col_ms > 0 else None,
+                                                "step": (moved[0] + moved[1]) / ((row_ms + col_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS if row_ms + col_ms > 0 else None},
                 "bytes_per_launch": dom[2],
                 "ms_per_launch": dom[1],
                 "rowpass": {"ms": row_ms, "bytes": row_b, "GBps": row_b / (row_ms * 1e-3) / 1e9 if row_ms > 0 else 0.0},
