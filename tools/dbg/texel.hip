@@ -28,6 +28,26 @@ __global__ void __launch_bounds__(512) mapstore(float4* __restrict__ maps, float
     __builtin_amdgcn_raw_buffer_store_b128(d, r, ob, 0, AUX);
   }
 }
+// 24-byte texels (dx, dy, dz, nx, ny, nz: the always-zero w components are not stored): a 4-column tile's row is 96 contiguous
+// bytes.  MODE 0: per lane 16 B (displacement + nx) then 8 B (ny, nz).  MODE 1: per lane 12 B then 12 B.
+typedef unsigned int u3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+template<int MODE, int AUX, int RUN>
+__global__ void __launch_bounds__(512) mapstore24(float* __restrict__ maps, float v) {
+  constexpr int TT = 512 / RUN, E2 = N / TT;
+  int c = blockIdx.y, tile = blockIdx.x; int cp = threadIdx.x % RUN, t = threadIdx.x / RUN;
+  size_t plane = (size_t)N * N; float* l0 = maps + (size_t)c * 6 * plane;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(l0, 0, (int)(6 * plane * 4), 0x00020000);
+  u4 d4 = { __float_as_uint(v), __float_as_uint(v + 1), __float_as_uint(v + 2), __float_as_uint(v + 3) };
+  u3 d3 = { d4.x, d4.y, d4.z }; u2 d2 = { d4.x, d4.y };
+  #pragma unroll
+  for (int s = 0; s < E2; ++s) {
+    int y = t + TT * s;
+    int o = (y * N + tile * RUN + cp) * 24;
+    if (MODE == 0) { __builtin_amdgcn_raw_buffer_store_b128(d4, r, o, 0, AUX); __builtin_amdgcn_raw_buffer_store_b64(d2, r, o + 16, 0, AUX); }
+    else { __builtin_amdgcn_raw_buffer_store_b96(d3, r, o, 0, AUX); __builtin_amdgcn_raw_buffer_store_b96(d3, r, o + 12, 0, AUX); }
+  }
+}
 int main() {
   size_t plane = (size_t)N*N;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -41,5 +61,11 @@ int main() {
   timeit("2-col tiles, quad-of-2 layout: 32-B run per instruction, sc0 sc1", mb, [&]{ hipLaunchKernelGGL((mapstore<0, 17, 2>), dim3(N/2, C), dim3(512), 0, 0, maps, 1.0f); });
   timeit("2-col tiles, texel layout: 16-B pieces at 32-B stride, plain", mb, [&]{ hipLaunchKernelGGL((mapstore<1, 0, 2>), dim3(N/2, C), dim3(512), 0, 0, maps, 1.0f); });
   timeit("8-col tiles, quad layout: 128-B run per instruction, sc0 sc1", mb, [&]{ hipLaunchKernelGGL((mapstore<0, 17, 8>), dim3(N/8, C), dim3(512), 0, 0, maps, 1.0f); });
+  { float* m24; CK(hipMalloc(&m24, C*6*plane*4)); double mb24 = 24.0*C*plane;
+    timeit("24-B texels, 4-col tiles: 16 B + 8 B per lane, plain", mb24, [&]{ hipLaunchKernelGGL((mapstore24<0, 0, 4>), dim3(N/4, C), dim3(512), 0, 0, m24, 1.0f); });
+    timeit("24-B texels, 4-col tiles: 16 B + 8 B per lane, sc0 sc1", mb24, [&]{ hipLaunchKernelGGL((mapstore24<0, 17, 4>), dim3(N/4, C), dim3(512), 0, 0, m24, 1.0f); });
+    timeit("24-B texels, 4-col tiles: 12 B + 12 B per lane, plain", mb24, [&]{ hipLaunchKernelGGL((mapstore24<1, 0, 4>), dim3(N/4, C), dim3(512), 0, 0, m24, 1.0f); });
+    timeit("24-B texels, 8-col tiles: 16 B + 8 B per lane, plain", mb24, [&]{ hipLaunchKernelGGL((mapstore24<0, 0, 8>), dim3(N/8, C), dim3(512), 0, 0, m24, 1.0f); });
+    timeit("24-B texels, 2-col tiles: 16 B + 8 B per lane, plain", mb24, [&]{ hipLaunchKernelGGL((mapstore24<0, 0, 2>), dim3(N/2, C), dim3(512), 0, 0, m24, 1.0f); }); }
   return 0;
 }
