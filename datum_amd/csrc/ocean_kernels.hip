@@ -1,4 +1,4 @@
-// ocean_kernels.hip -- gfx950 kernels of the ocean displacement step and mesh generation.
+// ocean_kernels.hip -- gfx950 kernels of the ocean displacement step (mesh generation: ocean_gen.hip).
 //
 // What the reference does in five Vulkan dispatches plus a host loop (src/renderer/ocean.cpp:217-236,
 // :769-793) is done here in two fused kernels (+ gen):
@@ -16,7 +16,9 @@
 // written moves 196.
 //
 // Work spectrum layout (private to these kernels): per cascade, 8 x 8 blocks of 16-byte values (C, D),
-// [y/8][x/8][y%8][x%8]: a row of a block is one 128-byte line; a column-pass wave reads whole blocks.
+// [y/8][x/8][y%8][x%8]: a row of a block is one 128-byte line; a column-pass wave reads whole blocks.  The largest grids
+// keep the columns one XCD works on at a time contiguous ([x/B][...]: blocked_at, band_cols), for the maps too (map_index).
+// From 2048^2 up the column pass's workgroups are persistent and walk their tiles, at 4096^2 the row pass's too.
 //
 // Built with -ffp-contract=off: products and sums are rounded as written (the phase state is
 // bit-identical to the host formula); the FFT butterflies ask for their FMAs explicitly.
