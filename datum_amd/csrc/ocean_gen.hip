@@ -44,6 +44,9 @@ namespace ocean
     int tilesx;
     int tiles;
     float *vertices;
+#ifdef OCEAN_STAMPS
+    unsigned long long *stamps;   // diagnostic builds only (tools/dbg/genstamps.hip): [workgroup][16] timestamps
+#endif
   };
 
   struct f3 { float x, y, z; };
@@ -116,6 +119,11 @@ namespace ocean
   // One vertex (xx, yy) of data/ocean.gen.comp:67-137.  Writes the vertex as three float4 into `out`.
   __device__ __forceinline__ void gen_vertex(GenArgs const &g, GlobalMap const &map, int xx, int yy, float4 (&out)[3])
   {
+#ifdef OCEAN_STAMPS
+    unsigned long long *stampbase = g.stamps + (size_t)blockIdx.x * 16;
+#endif
+    OCEAN_STAMP(0);
+
     datum_ocean_set const &p = g.set;
     GenFrame const &f = g.frame;
 
@@ -195,6 +203,8 @@ namespace ocean
     float4 a00 = zero, a10 = zero, a01 = zero, a11 = zero;
     float4 b00 = zero, b10 = zero, b01 = zero, b11 = zero;
 
+    OCEAN_STAMP(1);
+
 #ifdef OCEAN_GEN_ABLATE_LOADS      // timing-only builds (tools/): no map fetches
     a00 = a10 = a01 = a11 = make_float4(0.01f * (float)(i0 & 7), 0.02f, 0.03f * (float)(j0 & 3), 0.0f);
     b00 = b10 = b01 = b11 = make_float4(0.0f, 0.1f, 0.9f, 0.0f);
@@ -206,6 +216,9 @@ namespace ocean
     map.fetch(r1 + c0, w01 != 0.0f, shaded, a01, b01);
     map.fetch(r1 + c1, w11 != 0.0f, shaded, a11, b11);
 #endif
+
+    OCEAN_WAIT_LOADS();
+    OCEAN_STAMP(2);
 
     // (the sums below the base position are contracted into FMAs: the shading frame and the bilinear blend do not feed
     // an ill-conditioned step, and ocean.gen's tolerance is stated separately from the maps')
@@ -247,6 +260,8 @@ namespace ocean
 
     float d0 = tbn2.x;
     tbn0 = normalize3(f3{ 1 - d0 * tbn2.x, 0 - d0 * tbn2.y, 0 - d0 * tbn2.z });
+
+    OCEAN_STAMP(3);
 
     // Mesh::Vertex { position3, texcoord2, normal3, tangent4 } = 48 bytes (src/renderer/mesh.h:20-26)
     out[0] = make_float4(position.x - displacement.x, position.y - displacement.y, position.z + displacement.z, 0.1f * position.x);
@@ -307,5 +322,11 @@ namespace ocean
     float4 vtx[3];
     gen_vertex(g, map, tilex * GEN_TILE + (tid & 15), tiley * GEN_TILE + (tid >> 4), vtx);
     gen_store_tile(g, stage, tilex, tiley, tid, vtx);
+
+#ifdef OCEAN_STAMPS
+    unsigned long long *stampbase = g.stamps + (size_t)blockIdx.x * 16;
+#endif
+    OCEAN_STAMP_WHERE();
+    OCEAN_STAMP(4);
   }
 }
