@@ -406,13 +406,14 @@ def test_idempotent_without_update(capi, oracle):
 # -- ocean.gen -----------------------------------------------------------------------------------------------
 
 
-@pytest.mark.parametrize("N,size", [(64, 64), (64, 1024), (512, 256), (1024, 1024)])
+@pytest.mark.parametrize("N,size", [(64, 64), (64, 1024), (512, 256), (1024, 1024), (2048, 200), (4096, 96)])   # the last two: maps stored in bands of columns
 def test_gen_vertices(capi, oracle, torch, N, size):
     p = oracle.EXAMPLE
     h0 = make_state(oracle, N, 1000)
     s = oracle.example_oceanset(N, swellphase=0.7)
     hs = capi.OceanSet.from_buffer_copy(bytes(s))
     verts = torch.zeros(size * size * 12, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()              # torch's stream and the handle's own are not ordered
     with capi.Ocean(N, 1) as oc:
         oc.set_cascade(0, p["wavescale"], p["choppiness"])
         oc.upload_state(0, h0)
@@ -459,6 +460,7 @@ def test_bound_maps_and_caller_stream(capi, oracle, torch):
     p = oracle.EXAMPLE
     h0 = make_state(oracle, N, 77)
     buf = torch.zeros(2 * N * N * 4, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
     stream = torch.cuda.Stream()
     with capi.Ocean(N, 1) as oc:
         oc.set_cascade(0, p["wavescale"], p["choppiness"])
@@ -553,6 +555,7 @@ def test_gen_ragged_mesh(capi, oracle, torch):
     s = oracle.example_oceanset(N, swellphase=0.3)
     hs = capi.OceanSet.from_buffer_copy(bytes(s))
     verts = torch.full((sx * sy * 12 + 64,), 12345.0, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
     with capi.Ocean(N, 1) as oc:
         oc.set_cascade(0, p["wavescale"], p["choppiness"])
         oc.upload_state(0, h0)
@@ -626,7 +629,7 @@ def test_random_parameters(capi, oracle, case):
                 assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 2e-5
 
 
-@pytest.mark.parametrize("N,C", [(64, 2), (256, 3)])
+@pytest.mark.parametrize("N,C", [(64, 2), (256, 3), (2048, 1)])
 def test_pack_displacement_payloads(capi, oracle, torch, N, C):
     # the all-gather payloads (datum_ocean_pack_displacement): xyz32 is layer 0's (dx, dy, dz) bit for bit, xyz16 the same
     # rounded to halves with a zero fourth component, maps the map block as it lies in memory; a short buffer is refused
@@ -645,6 +648,7 @@ def test_pack_displacement_payloads(capi, oracle, torch, N, C):
             nbytes = oc.payload_bytes(code)
             assert nbytes == farm.payload_bytes(N, C, fmt)
             buf = torch.full((farm.payload_numel(N, C, fmt) + 16,), 7.0, dtype=dtype, device="cuda:0")
+            torch.cuda.synchronize()      # the fill ran on torch's stream, the pack runs on the handle's own
             oc.pack_displacement(code, buf.data_ptr(), nbytes)
             oc.sync()
             got = buf.cpu()
