@@ -83,19 +83,6 @@ def view_displacement(gathered, N, global_index, fmt):
     return gathered[global_index * n:(global_index + 1) * n].view(N, N, per)[..., :3]
 
 
-def pack_host(logical_maps, fmt):
-    """The payload datum_ocean_pack_displacement produces, built on the host from LOGICAL maps ([grids][2][N][N][4]).
-    Only the CPU tests use it (the oracle stands in for a rank's GPU there); "maps" is not offered because the device
-    layout of the map block is the kernels' own."""
-    disp = logical_maps[:, 0, :, :, :3]
-    if fmt == "xyz32":
-        return disp.contiguous().reshape(-1).to(torch.float32)
-    if fmt == "xyz16":
-        z = torch.zeros(disp.shape[:-1] + (1,), dtype=disp.dtype)
-        return torch.cat([disp, z], -1).to(torch.float16).reshape(-1)
-    raise ValueError(fmt)
-
-
 class TileGather:
     """Double-buffered, overlapped all-gather of the ranks' payloads.
 

@@ -12,6 +12,18 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+def pack_host(logical_maps, fmt):
+    """The payload datum_ocean_pack_displacement produces (include/datum_ocean_hip.h), built here from LOGICAL maps
+    ([grids][2][N][N][4]) for the CPU tests, where the oracle stands in for a rank's GPU."""
+    disp = logical_maps[:, 0, :, :, :3]
+    if fmt == "xyz32":
+        return disp.contiguous().reshape(-1).to(torch.float32)
+    if fmt == "xyz16":
+        z = torch.zeros(disp.shape[:-1] + (1,), dtype=disp.dtype)
+        return torch.cat([disp, z], -1).to(torch.float16).reshape(-1)
+    raise ValueError(fmt)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -100,7 +112,7 @@ def _pipeline_worker(rank, world, port, N, per_rank, fmt, batches, q):
         for b in range(batches):
             for i, (h0, phase, ws) in enumerate(states):  # "batch b": one more step of every owned grid
                 maps[i].copy_(torch.from_numpy(oracle.displace(h0, phase, ws, 1.35, dt=np.float32(1 / 60))))
-            tg.acquire().copy_(farm.pack_host(maps, fmt))
+            tg.acquire().copy_(pack_host(maps, fmt))
             tg.launch()                                   # returns at once; the next batch overwrites `maps` meanwhile
             if b >= 1:
                 out = tg.result()                         # batch b - 1
