@@ -54,7 +54,7 @@ SYMBOLS = {
     "datum_ocean_set_stream": (I, [P, P, I]),
     "datum_ocean_bind_maps": (I, [P, P, ctypes.c_size_t]),
     "datum_ocean_maps_device": (I, [P, ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]),
-    "datum_ocean_map_layout": (I, [I, ctypes.POINTER(I), ctypes.POINTER(I)]),
+    "datum_ocean_map_layout": (I, [I, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(I)]),
     "datum_ocean_set_cascade": (I, [P, I, F, F]),
     "datum_ocean_set_spectrum_format": (I, [P, I]),
     "datum_ocean_upload_state": (I, [P, I, P, P]),
@@ -279,23 +279,24 @@ class Ocean:
 
 
 def map_layout(N):
-    """(G, B) of the device map layout at resolution N (include/datum_ocean_hip.h: datum_ocean_bind_maps)."""
-    g, b = I(), I()
-    rc = load().datum_ocean_map_layout(N, ctypes.byref(g), ctypes.byref(b))
+    """(GX, GY, B) of the device map layout at resolution N (include/datum_ocean_hip.h: datum_ocean_bind_maps)."""
+    gx, gy, b = I(), I(), I()
+    rc = load().datum_ocean_map_layout(N, ctypes.byref(gx), ctypes.byref(gy), ctypes.byref(b))
     if rc != 0:
         raise OceanError(rc, load().datum_ocean_last_error(None).decode())
-    return g.value, b.value
+    return gx.value, gy.value, b.value
 
 
 def map_layers(raw, N):
-    """View of one cascade's DEVICE map block (2*N*N*4 floats as the kernels lay them out: bands of B columns, per row
-    groups of G texels, layer 0 of the group then layer 1 of the group -- include/datum_ocean_hip.h) as the reference's
+    """View of one cascade's DEVICE map block (2*N*N*4 floats as the kernels lay them out: bands of B columns, groups of
+    GX x GY texels, layer 0 of the group then layer 1 of the group -- include/datum_ocean_hip.h) as the reference's
     logical image [layer][y][x][4].  Works on numpy arrays and torch tensors alike (reshape / permute only)."""
-    G, B = map_layout(N)
-    v = raw.reshape(N // B, N, B // G, 2, G, 4)          # [band][y][group][layer][x % G][component]
+    GX, GY, B = map_layout(N)
+    v = raw.reshape(N // B, N // GY, B // GX, 2, GY, GX, 4)   # [band][y / GY][group][layer][y % GY][x % GX][component]
+    order = (3, 1, 4, 0, 2, 5, 6)                              # -> [layer][y / GY][y % GY][band][group][x % GX][component]
     if hasattr(v, "permute"):
-        return v.permute(3, 1, 0, 2, 4, 5).reshape(2, N, N, 4)
-    return v.transpose(3, 1, 0, 2, 4, 5).reshape(2, N, N, 4)
+        return v.permute(*order).reshape(2, N, N, 4)
+    return v.transpose(*order).reshape(2, N, N, 4)
 
 
 def reference_weights(N):

@@ -161,7 +161,9 @@ namespace
     // compute unit that walks its share
     int const items = RowCfg<N>::GROUPS * ctx->cascades;
 
-    return launch(kernel, dim3(row_walks<N>() ? std::min(items, ctx->cus) : items), dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream, ev);
+    int const percu = RowCfg<N>::PER_CU;
+
+    return launch(kernel, dim3(row_walks<N>() ? std::min(items, ctx->cus * percu) : items), dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream, ev);
   }
 
   template<int N>
@@ -517,12 +519,13 @@ int datum_ocean_maps_device(datum_ocean_t ctx, void **device_ptr, size_t *bytes)
   return DATUM_OCEAN_OK;
 }
 
-int datum_ocean_map_layout(int resolution, int *group, int *band)
+int datum_ocean_map_layout(int resolution, int *group_cols, int *group_rows, int *band)
 {
-  if (!supported(resolution) || !group || !band)
+  if (!supported(resolution) || !group_cols || !group_rows || !band)
     return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_map_layout: bad argument");
 
-  *group = MAP_GROUP;
+  *group_cols = map_group_cols(resolution);
+  *group_rows = map_group_rows(resolution);
   *band = band_cols(resolution);
 
   return DATUM_OCEAN_OK;

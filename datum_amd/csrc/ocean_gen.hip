@@ -190,11 +190,12 @@ namespace ocean
 
     float const w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
 
-    // map_index, rows and columns apart (large maps are stored in bands of columns)
+    // map_index, rows and columns apart (large maps are stored in bands of columns; groups of GX x GY texels)
     int const B = band_cols(N);
-    int const r0 = j0 * 2 * B, r1 = j1 * 2 * B;
-    int const c0 = (i0 / B) * 2 * N * B + ((i0 % B) / MAP_GROUP) * (2 * MAP_GROUP) + (i0 % MAP_GROUP);
-    int const c1 = (i1 / B) * 2 * N * B + ((i1 % B) / MAP_GROUP) * (2 * MAP_GROUP) + (i1 % MAP_GROUP);
+    int const GX = map_group_cols(N), GY = map_group_rows(N);
+    int const r0 = (j0 / GY) * 2 * GY * B + (j0 % GY) * GX, r1 = (j1 / GY) * 2 * GY * B + (j1 % GY) * GX;
+    int const c0 = (i0 / B) * 2 * N * B + ((i0 % B) / GX) * (2 * MAP_GROUP) + (i0 % GX);
+    int const c1 = (i1 / B) * 2 * N * B + ((i1 % B) / GX) * (2 * MAP_GROUP) + (i1 % GX);
 
     bool const shaded = smoothing != 1.0f;       // otherwise the sampled normal is multiplied by an exact 0
 

@@ -96,9 +96,10 @@ namespace ocean
   // memory -- [x / B][rows][x % B] -- for the work spectrum and for the maps alike, so that what is read and written
   // concurrently is a dense region instead of 2 KB pieces of rows 128 KB apart (4096^2).  B = band_cols(N), 0 = whole rows.
   // measured (profiles/r02_large_grids.txt): 4096^2 B = 64 (32 CUs x 2-column tiles): column pass 240 -> 226 us, with the
-  // fp16-stored spectrum 202 -> 164 us; 2048^2 x 4 B = 128 (32 CUs x 4-column tiles): 181 -> 167 us; B = 512 at 4096^2: 270 us
+  // fp16-stored spectrum 202 -> 164 us; 2048^2 x 4 B = 128 (32 CUs x 4-column tiles): 181 -> 167 us; B = 512 at 4096^2: 270 us.
+  // With the maps in 2 x 2 patches at 4096^2 (map_index): B = 64 184-195 us, B = 128 176-183 us, B = 256 192 us, B = 512 / none 220 us
 #ifndef OCEAN_BAND_COLS_4096
-#define OCEAN_BAND_COLS_4096 64
+#define OCEAN_BAND_COLS_4096 128
 #endif
 #ifndef OCEAN_BAND_COLS_2048
 #define OCEAN_BAND_COLS_2048 128
@@ -120,26 +121,37 @@ namespace ocean
   }
 
   // Displacement map layout (private to this module: in the reference the map is a VK_IMAGE_TILING_OPTIMAL 2-layer
-  // image whose only reader is ocean.gen's sampler, ocean.cpp:706, gen.comp:113-114).  Per cascade, per row y, groups of
-  // G = OCEAN_MAP_GROUP texels: 16 G bytes of layer 0 (displacement) of texels G g .. G g + G - 1, then 16 G bytes of
-  // layer 1 (normal) of the same texels, so that a bilinear corner of ocean.gen finds its displacement and its normal in
-  // one cache line instead of two lines 16 N^2 bytes apart.  G = 4: one 128-byte line holds both layers of four
-  // neighbouring texels and a store instruction of a four-column tile writes a 64-byte run.  G = 1: the two layers of a
-  // texel are adjacent (32 bytes).
+  // image whose only reader is ocean.gen's sampler, ocean.cpp:706, gen.comp:113-114).  Per cascade, groups of four
+  // texels: 64 bytes of layer 0 (displacement) of the four, then 64 bytes of layer 1 (normal) of the same four, so that
+  // one 128-byte line holds both layers of four neighbouring texels: a bilinear corner of ocean.gen finds its
+  // displacement and its normal in one cache line instead of two lines 16 N^2 bytes apart.
+  // A group is GX x GY texels (map_group_cols / map_group_rows):
+  //   4 x 1 up to 2048^2 -- four neighbours of a row: the column pass's four-column tiles write whole lines;
+  //   2 x 2 at 4096^2    -- a patch of two rows: there the tiles are TWO columns wide (LDS), and with 4 x 1 groups their
+  //                         stores were 32-byte pieces of lines that the neighbouring tile completes (3.3 TB/s); four lanes
+  //                         = two rows of two columns now fill a 64-byte half line per store instruction, the pair of
+  //                         instructions a line (memory skeleton of the pass, tools/dbg/band.hip: 193 -> 159 us).
 #ifndef OCEAN_MAP_GROUP
 #define OCEAN_MAP_GROUP 4
 #endif
-  constexpr int MAP_GROUP = OCEAN_MAP_GROUP;
+#ifndef OCEAN_MAP_PATCH_FROM
+#define OCEAN_MAP_PATCH_FROM 4096
+#endif
+  constexpr int MAP_GROUP = OCEAN_MAP_GROUP;      // texels per group = float4 from a group's layer 0 to its layer 1
 
-  // float4 index of texel (x, y) of `layer` (bands as for the spectrum: [x / B][y][groups of the band's row]):
+  __host__ __device__ __forceinline__ constexpr int map_group_rows(int N) { return (MAP_GROUP == 4 && N >= OCEAN_MAP_PATCH_FROM) ? 2 : 1; }
+  __host__ __device__ __forceinline__ constexpr int map_group_cols(int N) { return MAP_GROUP / map_group_rows(N); }
+
+  // float4 index of texel (x, y) of `layer` (bands as for the spectrum: [x / B][y / GY][groups of the band's rows]):
   __host__ __device__ __forceinline__ constexpr size_t map_index(int N, int y, int x, int layer)
   {
     int const B = band_cols(N);
+    int const GX = map_group_cols(N), GY = map_group_rows(N);
 
-    return (size_t)(x / B) * 2 * N * B + (size_t)y * 2 * B + (size_t)((x % B) / MAP_GROUP) * (2 * MAP_GROUP) + layer * MAP_GROUP + (x % MAP_GROUP);
+    return (size_t)(x / B) * 2 * N * B + ((size_t)(y / GY) * (B / GX) + (x % B) / GX) * (2 * MAP_GROUP) + layer * MAP_GROUP + (y % GY) * GX + (x % GX);
   }
 
-  // float4 from one row of the maps to the next (same column)
+  // float4 per row of a band: from a texel to the same column map_group_rows(N) * k rows on it is k * map_group_rows(N) * map_row_pitch(N)
   __host__ __device__ __forceinline__ constexpr int map_row_pitch(int N) { return 2 * band_cols(N); }
 
   //|---------------------- buffer addressing ----------------------------------
@@ -527,6 +539,12 @@ namespace ocean
 #ifndef OCEAN_ROW_WALK_FROM
 #define OCEAN_ROW_WALK_FROM 4096
 #endif
+#ifndef OCEAN_ROW_EARLY_AT
+#define OCEAN_ROW_EARLY_AT 0
+#endif
+#ifndef OCEAN_ROW_EARLY
+#define OCEAN_ROW_EARLY 3          // walking row pass: the parts of the next pair's inputs requested BEFORE the transforms (see request): h0 and its mirror row
+#endif
 
   template<int N>
   struct RowCfg
@@ -544,6 +562,9 @@ namespace ocean
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
     static constexpr bool WALK = (N >= OCEAN_ROW_WALK_FROM) && PAIRS == 1;       // see ocean_rowpass_kernel
     static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)4 * T : 0)) * sizeof(cf);      // + the walking variant's twiddle stash
+
+    static constexpr int PER_CU = (LDS * 2 <= (size_t)160 * 1024) ? 2 : 1;                     // persistent workgroups per compute unit (walking)
+    static constexpr int MIN_WAVES = WALK ? (THREADS / 64) * PER_CU / 4 : 1;                    // per SIMD, for __launch_bounds__
 
     static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
   };
@@ -593,7 +614,7 @@ namespace ocean
   template<int N> constexpr bool row_walks() { return RowCfg<N>::WALK; }
 
   template<int N, bool H16>
-  __global__ void __launch_bounds__(RowCfg<N>::THREADS) ocean_rowpass_kernel(StepArgs a)
+  __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) ocean_rowpass_kernel(StepArgs a)
   {
     typedef Plan<N> P;
     typedef LineFFT<N> L;
@@ -643,7 +664,8 @@ namespace ocean
       float2 hk[E], hm[E];
     };
 
-    auto request = [&](int item, int t, Inputs &in)
+    // parts: 1 = h0, 2 = h0's mirror row, 4 = phase, 8 = dispersion
+    auto request = [&](int item, int t, Inputs &in, int parts = 15)
     {
       int const cascade = item / G;
       int const y = row_of(item);
@@ -665,13 +687,16 @@ namespace ocean
         in.hk[s] = make_float2(0.01f * (float)((t + s) & 15), 0.02f);
         in.hm[s] = make_float2(0.03f, 0.01f * (float)(y & 15));
 #else
-        in.ph[s] = buf_load_f32(rphase, e0 * 4, T * s * 4);
-        in.hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
-        in.hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
+        if (parts & 4)
+          in.ph[s] = buf_load_f32(rphase, e0 * 4, T * s * 4);
+        if (parts & 1)
+          in.hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
+        if (parts & 2)
+          in.hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
 #endif
       }
 
-      if (advance)
+      if (advance && (parts & 8))
       {
         #pragma unroll
         for(int s = 0; s < E; ++s)
@@ -809,6 +834,9 @@ namespace ocean
         swap_out[padidx<C::PS>(t + T * s)] = h[s];
       }
 
+      if constexpr (WALK && OCEAN_ROW_EARLY != 0 && OCEAN_ROW_EARLY_AT == 1)
+        request(next, t, in, OCEAN_ROW_EARLY);
+
       __syncthreads();
 
       OCEAN_STAMP(2);
@@ -851,12 +879,15 @@ namespace ocean
 
       OCEAN_STAMP(3);
 
+      if constexpr (WALK && OCEAN_ROW_EARLY != 0 && OCEAN_ROW_EARLY_AT == 0)
+        request(next, t, in, OCEAN_ROW_EARLY);
+
 #ifndef OCEAN_ABLATE_ROWFFT
       fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
 #endif
 
-      if constexpr (WALK)
-        request(next, t, in);
+      if constexpr (WALK && OCEAN_ROW_EARLY != 15)
+        request(next, t, in, 15 & ~OCEAN_ROW_EARLY);
 
       OCEAN_STAMP(4);
 
@@ -1188,7 +1219,7 @@ namespace ocean
 #ifndef OCEAN_COL_LINE_STORES
 #define OCEAN_COL_LINE_STORES 1
 #endif
-          if constexpr (OCEAN_COL_LINE_STORES && W == 4 && MAP_GROUP == 4)
+          if constexpr (OCEAN_COL_LINE_STORES && W == 4 && MAP_GROUP == 4 && map_group_rows(N) == 1)
           {
             // Lanes 4 k .. 4 k + 3 of a wave hold the four texels of row t, the next four lanes those of row t + 1.  The
             // two rows trade halves (DPP row shifts by four lanes), so that ONE store instruction writes a row's whole

@@ -80,12 +80,14 @@ int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream, int use_own);
  * handle's own buffer.
  * DEVICE LAYOUT of a cascade's map block (the reference's displacementmap is a VK_IMAGE_TILING_OPTIMAL image,
  * ocean.cpp:706, whose physical layout is the driver's; its only reader is ocean.gen): bands of B columns (B = N
- * except for the largest grids), per band row after row, per row groups of G texels: 4 G floats of layer 0 (texels
- * G g .. G g + G - 1: dx, dy, dz, 0) followed by 4 G floats of layer 1 (the same texels: nx, ny, nz, 0).  float4 index of
- * texel (x, y, layer) = (x / B) * 2 N B + y * 2 B + ((x % B) / G) * 2 G + layer * G + x % G, with (G, B) from
- * datum_ocean_map_layout.  datum_ocean_read_maps returns the logical image [layer][y][x][4]. */
+ * except for the largest grids); inside a band groups of GX x GY texels (4 x 1: four neighbours of a row; 2 x 2 at
+ * 4096: a patch of two rows), group rows one after the other; a group is one 128-byte line: 16 floats of layer 0
+ * (its texels row by row: dx, dy, dz, 0) followed by 16 floats of layer 1 (the same texels: nx, ny, nz, 0).
+ * float4 index of texel (x, y, layer)
+ *   = (x / B) * 2 N B + ((y / GY) * (B / GX) + (x % B) / GX) * 8 + layer * 4 + (y % GY) * GX + x % GX,
+ * with (GX, GY, B) from datum_ocean_map_layout.  datum_ocean_read_maps returns the logical image [layer][y][x][4]. */
 int datum_ocean_bind_maps(datum_ocean_t ctx, void *device_ptr, size_t bytes);
-int datum_ocean_map_layout(int resolution, int *group, int *band);
+int datum_ocean_map_layout(int resolution, int *group_cols, int *group_rows, int *band);
 int datum_ocean_maps_device(datum_ocean_t ctx, void **device_ptr, size_t *bytes);
 
 /* -- state (OceanParams arrays, ocean.h:67-72) ------------------------------------------------------- */

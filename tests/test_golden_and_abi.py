@@ -87,6 +87,28 @@ def test_abi_argument_errors_without_gpu():
     assert lib.datum_ocean_destroy(None) == capi.OK
 
 
+@pytest.mark.parametrize("N", [64, 256, 1024, 2048, 4096])
+def test_map_layout_formula_and_view(N):
+    # the documented index formula of include/datum_ocean_hip.h (datum_ocean_bind_maps) against capi.map_layers, no GPU
+    from datum_amd import capi
+
+    GX, GY, B = capi.map_layout(N)
+    assert GX * GY == 4 and N % B == 0 and B % GX == 0
+    assert (GX, GY) == ((2, 2) if N == 4096 else (4, 1))
+
+    rs = np.random.RandomState(N)
+    ys, xs = rs.randint(0, N, 4096), rs.randint(0, N, 4096)
+    ys[:4], xs[:4] = [0, 0, N - 1, N - 1], [0, N - 1, 0, N - 1]
+    raw = np.zeros(2 * N * N, np.int64)                       # one id per float4
+    for layer in (0, 1):
+        idx = (xs // B) * 2 * N * B + ((ys // GY) * (B // GX) + (xs % B) // GX) * 8 + layer * 4 + (ys % GY) * GX + xs % GX
+        raw[idx] = 1 + layer * N * N + ys * N + xs
+    view = capi.map_layers(np.repeat(raw, 4), N)
+    for layer in (0, 1):
+        assert np.array_equal(view[layer, ys, xs, 0], 1 + layer * N * N + ys * N + xs)
+    assert np.count_nonzero(view[..., 0]) == np.count_nonzero(raw)
+
+
 def test_reference_weights_match_oracle(oracle):
     from datum_amd import capi
 

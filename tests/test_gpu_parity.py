@@ -454,9 +454,9 @@ def test_error_codes(capi):
         capi.Ocean(96, 1)
 
 
-def test_bound_maps_and_caller_stream(capi, oracle, torch):
+@pytest.mark.parametrize("N", [256, 2048, 4096])       # 4 x 1 groups, bands, bands of 2 x 2 patches
+def test_bound_maps_and_caller_stream(capi, oracle, torch, N):
     # maps written straight into a caller-owned device buffer on the caller's stream (the all-gather path)
-    N = 256
     p = oracle.EXAMPLE
     h0 = make_state(oracle, N, 77)
     buf = torch.zeros(2 * N * N * 4, dtype=torch.float32, device="cuda:0")

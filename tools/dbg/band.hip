@@ -19,7 +19,12 @@ template<int BAND> __device__ __forceinline__ size_t spec_at(int y, int x) {
   int b = x / BAND, xi = x % BAND;
   return (size_t)b * N * BAND + (((size_t)((y >> 3) * (BAND / 8) + (xi >> 3))) << 6) + ((y & 7) << 3) + (xi & 7);
 }
-template<int BAND, bool LOADS, bool STORES>
+// 2 x 2 texel patches: one 128-byte line = layer 0 of (y, x), (y, x+1), (y+1, x), (y+1, x+1), then layer 1 of the same four; bands of BAND columns
+template<int BAND> __device__ __forceinline__ size_t patch_at(int y, int x, int layer) {
+  int b = x / BAND, xi = x % BAND;
+  return (size_t)b * 2 * N * BAND + ((size_t)(y >> 1) * (BAND / 2) + (xi >> 1)) * 8 + layer * 4 + (y & 1) * 2 + (xi & 1);
+}
+template<int BAND, bool LOADS, bool STORES, int PATCH = 0>
 __global__ void __launch_bounds__(1024) colmem(float4 const* __restrict__ spec, float4* __restrict__ maps, float* sink, int groups) {
   int cp = threadIdx.x % W, t = threadIdx.x / W;
   float acc = 0;
@@ -37,7 +42,14 @@ __global__ void __launch_bounds__(1024) colmem(float4 const* __restrict__ spec, 
     if (STORES) {
       #pragma unroll
       for (int s = 0; s < E; ++s) {
-        if (BAND == -3) {
+        if (PATCH == 1) {
+          maps[patch_at<BAND>(t + T * s, x, 0)] = v[s];
+          maps[patch_at<BAND>(t + T * s, x, 1)] = make_float4(v[s].y, v[s].x, v[s].w, 0.0f);
+        } else if (PATCH == 2) {
+          // four lanes = one patch; the even quad of lanes writes the displacement half, the odd quad the normal half: one instruction = whole lines
+          maps[patch_at<BAND>(((t & ~3) | (t & 1)) + T * s, x, (t >> 1) & 1)] = v[s];
+          maps[patch_at<BAND>(((t & ~3) | 2 | (t & 1)) + T * s, x, (t >> 1) & 1)] = make_float4(v[s].y, v[s].x, v[s].w, 0.0f);
+        } else if (BAND == -3) {
           // one instruction = the 64-byte run of ONE row: lanes of the even row write its displacement pair, lanes of the odd row its normal pair
           maps[map_at<BAND>((t & ~1) + T * s, x, t & 1)] = v[s];
           maps[map_at<BAND>((t | 1) + T * s, x, t & 1)] = make_float4(v[s].y, v[s].x, v[s].w, 0.0f);
@@ -84,6 +96,12 @@ int main() {
     timeit("512-column bands: stores only", sb, [&]{ hipLaunchKernelGGL((colmem<512, false, true>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
     timeit("512-column bands: loads + stores", lb + sb, [&]{ hipLaunchKernelGGL((colmem<512, true, true>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
     timeit("64-column bands: loads + stores", lb + sb, [&]{ hipLaunchKernelGGL((colmem<64, true, true>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
+    timeit("64-column bands: stores only", sb, [&]{ hipLaunchKernelGGL((colmem<64, false, true>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
+    timeit("2x2 patches, 64-column bands, half lines per instruction: stores only", sb, [&]{ hipLaunchKernelGGL((colmem<64, false, true, 1>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
+    timeit("2x2 patches, 64-column bands, whole lines per instruction: stores only", sb, [&]{ hipLaunchKernelGGL((colmem<64, false, true, 2>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
+    timeit("2x2 patches, 64-column bands, whole lines per instruction: loads + stores", lb + sb, [&]{ hipLaunchKernelGGL((colmem<64, true, true, 2>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
+    timeit("2x2 patches, 128-column bands, whole lines per instruction: loads + stores", lb + sb, [&]{ hipLaunchKernelGGL((colmem<128, true, true, 2>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
+    timeit("2x2 patches, 32-column bands, whole lines per instruction: loads + stores", lb + sb, [&]{ hipLaunchKernelGGL((colmem<32, true, true, 2>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
     timeit("texel pairs (64 B per tile row, two 32-B instructions): stores only", sb, [&]{ hipLaunchKernelGGL((colmem<-2, false, true>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
     timeit("texel pairs, one 64-B run per instruction: stores only", sb, [&]{ hipLaunchKernelGGL((colmem<-3, false, true>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
     timeit("texel pairs, one 64-B run per instruction: loads + stores", lb + sb, [&]{ hipLaunchKernelGGL((colmem<-3, true, true>), dim3(groups), dim3(1024), 0, 0, spec, maps, sink, groups); });
