@@ -539,6 +539,9 @@ namespace ocean
 #ifndef OCEAN_ROW_WALK_FROM
 #define OCEAN_ROW_WALK_FROM 4096
 #endif
+#ifndef OCEAN_ROW_REST_IN_HOOK
+#define OCEAN_ROW_REST_IN_HOOK 1
+#endif
 #ifndef OCEAN_ROW_EARLY_AT
 #define OCEAN_ROW_EARLY_AT 0
 #endif
@@ -882,11 +885,20 @@ namespace ocean
       if constexpr (WALK && OCEAN_ROW_EARLY != 0 && OCEAN_ROW_EARLY_AT == 0)
         request(next, t, in, OCEAN_ROW_EARLY);
 
+      // the rest between the last exchange and the last pass, where the value registers are free
+      auto rest = [&]()
+      {
+        if constexpr (WALK && OCEAN_ROW_EARLY != 15 && OCEAN_ROW_REST_IN_HOOK)
+          request(next, t, in, 15 & ~OCEAN_ROW_EARLY);
+      };
+
 #ifndef OCEAN_ABLATE_ROWFFT
-      fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true);
+      fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true, rest);
+#else
+      rest();
 #endif
 
-      if constexpr (WALK && OCEAN_ROW_EARLY != 15)
+      if constexpr (WALK && OCEAN_ROW_EARLY != 15 && !OCEAN_ROW_REST_IN_HOOK)
         request(next, t, in, 15 & ~OCEAN_ROW_EARLY);
 
       OCEAN_STAMP(4);
