@@ -190,12 +190,17 @@ namespace ocean
 
     float const w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
 
-    // map_index, rows and columns apart (large maps are stored in bands of columns; groups of GX x GY texels)
-    int const B = band_cols(N);
-    int const GX = map_group_cols(N), GY = map_group_rows(N);
-    int const r0 = (j0 / GY) * 2 * GY * B + (j0 % GY) * GX, r1 = (j1 / GY) * 2 * GY * B + (j1 % GY) * GX;
-    int const c0 = (i0 / B) * 2 * N * B + ((i0 % B) / GX) * (2 * MAP_GROUP) + (i0 % GX);
-    int const c1 = (i1 / B) * 2 * N * B + ((i1 % B) / GX) * (2 * MAP_GROUP) + (i1 % GX);
+    // map_index, rows and columns apart (large maps are stored in bands of columns; groups of GX x GY texels).  Every
+    // extent is a power of two: shifts by wave-uniform amounts (divisions by run-time values cost some 30 instructions each)
+    int const lb = 31 - __builtin_clz(band_cols(N)), ln = 31 - __builtin_clz(N);
+    int const lgx = 31 - __builtin_clz(map_group_cols(N)), lgy = 31 - __builtin_clz(map_group_rows(N));
+    int const bmask = (1 << lb) - 1, xmask = (1 << lgx) - 1, ymask = (1 << lgy) - 1;
+
+    int const r0 = ((j0 >> lgy) << (1 + lgy + lb)) + ((j0 & ymask) << lgx), r1 = ((j1 >> lgy) << (1 + lgy + lb)) + ((j1 & ymask) << lgx);
+    int const c0 = ((i0 >> lb) << (1 + ln + lb)) + (((i0 & bmask) >> lgx) << 3) + (i0 & xmask);
+    int const c1 = ((i1 >> lb) << (1 + ln + lb)) + (((i1 & bmask) >> lgx) << 3) + (i1 & xmask);
+
+    static_assert(MAP_GROUP == 4, "a group is one 128-byte line: 8 float4");
 
     bool const shaded = smoothing != 1.0f;       // otherwise the sampled normal is multiplied by an exact 0
 
