@@ -131,12 +131,15 @@ namespace ocean
 #define OCEAN_FFT_E 8
 #endif
 
-  template<int N>
+  // points per thread of a line transform unless the caller chooses (the kernels do, per pass: RowCfg / ColCfg)
+  constexpr int default_radix(int n) { return n == 64 ? 4 : OCEAN_FFT_E; }
+
+  template<int N, int E_ = default_radix(N)>
   struct Plan
   {
     static_assert(N == 64 || N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096, "unsupported resolution");
 
-    static constexpr int E = (N == 64) ? 4 : OCEAN_FFT_E;
+    static constexpr int E = E_;
     static constexpr int T = N / E;
     static constexpr int NP = plan_passes(N, E);
     static constexpr int RL = N / ipow(E, NP - 1);
@@ -292,19 +295,19 @@ namespace ocean
   // per-thread twiddles kept in registers, each the first power of its pass; higher powers come from
   // twiddle_powers.  last[m] = exp(2 pi i j / N) for the last pass's tasks j = t + T m (Ns = N / RL);
   // mid[k] = exp(2 pi i (t % Ns) / (Ns E)) for middle pass k + 2 (Ns = E^(k+2)).
-  template<int N>
+  template<int N, int E_ = default_radix(N)>
   struct LineTwiddles
   {
-    static constexpr int NMIDREG = (Plan<N>::NP > 3) ? Plan<N>::NP - 3 : 1;
+    static constexpr int NMIDREG = (Plan<N, E_>::NP > 3) ? Plan<N, E_>::NP - 3 : 1;
 
     cf mid[NMIDREG];
-    cf last[Plan<N>::M];
+    cf last[Plan<N, E_>::M];
   };
 
-  template<int N, int PS = 4>
+  template<int N, int PS = 4, int E_ = default_radix(N)>
   struct LineFFT
   {
-    typedef Plan<N> P;
+    typedef Plan<N, E_> P;
 
     static constexpr int LINE = P::template line<PS>();
 
@@ -316,9 +319,9 @@ namespace ocean
     // per-thread twiddles kept in registers, each the first power of its pass; higher powers come from
     // twiddle_powers.  last[m] = exp(2 pi i j / N) for the last pass's tasks j = t + T m (Ns = N / RL);
     // mid[k] = exp(2 pi i (t % Ns) / (Ns E)) for middle pass k + 2 (Ns = E^(k+2)).
-    static constexpr int NMIDREG = LineTwiddles<N>::NMIDREG;
+    static constexpr int NMIDREG = LineTwiddles<N, E_>::NMIDREG;
 
-    typedef LineTwiddles<N> Twiddles;
+    typedef LineTwiddles<N, E_> Twiddles;
 
     static OC_HD void load_twiddles(cf const *tw, int t, Twiddles &w)
     {
@@ -426,6 +429,6 @@ namespace ocean
   };
 
   // element a thread holds in slot s before / after a line transform
-  template<int N> OC_HD constexpr int elem_in(int t, int s) { return t + Plan<N>::T * s; }
-  template<int N> OC_HD constexpr int elem_out(int t, int s) { return t + Plan<N>::T * s; }
+  template<int N, int E_ = default_radix(N)> OC_HD constexpr int elem_in(int t, int s) { return t + Plan<N, E_>::T * s; }
+  template<int N, int E_ = default_radix(N)> OC_HD constexpr int elem_out(int t, int s) { return t + Plan<N, E_>::T * s; }
 }

@@ -390,10 +390,10 @@ namespace ocean
 
   //|---------------------- per-thread twiddles of a line transform ------------
 
-  template<int N> struct LineTw
+  template<int N, int E_> struct LineTw
   {
-    typedef typename LineFFT<N>::Twiddles type;
-    static __device__ __forceinline__ void load(cf const *tw, int t, type &w) { LineFFT<N>::load_twiddles(tw, t, w); }
+    typedef typename LineFFT<N, 4, E_>::Twiddles type;
+    static __device__ __forceinline__ void load(cf const *tw, int t, type &w) { LineFFT<N, 4, E_>::load_twiddles(tw, t, w); }
   };
 
   //|---------------------- line FFTs with workgroup barriers ------------------
@@ -404,10 +404,10 @@ namespace ocean
 
   // `before_last` runs between the last exchange and the last pass: every value of the lines is in LDS then and the
   // threads' value registers are free (the walking column pass requests its next tile there)
-  template<int N, int K, int PS, typename Hook = NoHook>
-  __device__ __forceinline__ void fft_lines(cf (&v)[K][Plan<N>::E], int t, cf *line, int linestride, cf const *midtab, typename LineTw<N>::type const &w, bool active, Hook before_last = Hook())
+  template<int N, int K, int PS, int E_, typename Hook = NoHook>
+  __device__ __forceinline__ void fft_lines(cf (&v)[K][E_], int t, cf *line, int linestride, cf const *midtab, typename LineTw<N, E_>::type const &w, bool active, Hook before_last = Hook())
   {
-    typedef LineFFT<N, PS> L;
+    typedef LineFFT<N, PS, E_> L;
 
     if (active)
     {
@@ -418,7 +418,7 @@ namespace ocean
 
     __syncthreads();
 
-    if (Plan<N>::NP >= 3)
+    if (Plan<N, E_>::NP >= 3)
     {
       if (active)
       {
@@ -439,7 +439,7 @@ namespace ocean
       __syncthreads();
     }
 
-    if (Plan<N>::NP >= 4)
+    if (Plan<N, E_>::NP >= 4)
     {
       if (active)
       {
@@ -460,7 +460,7 @@ namespace ocean
       __syncthreads();
     }
 
-    if (Plan<N>::NP >= 5)
+    if (Plan<N, E_>::NP >= 5)
     {
       if (active)
       {
@@ -481,7 +481,7 @@ namespace ocean
       __syncthreads();
     }
 
-    if (Plan<N>::NP >= 6)
+    if (Plan<N, E_>::NP >= 6)
     {
       if (active)
       {
@@ -552,8 +552,8 @@ namespace ocean
   template<int N>
   struct RowCfg
   {
-    static constexpr int E = Plan<N>::E;
-    static constexpr int T = Plan<N>::T;
+    static constexpr int E = default_radix(N);
+    static constexpr int T = Plan<N, E>::T;
 #ifndef OCEAN_ROW_PAIR_THREADS
 #define OCEAN_ROW_PAIR_THREADS 128   // threads of a row-pass workgroup when one row pair needs fewer (small grids are
 #endif                               // latency-bound: more, smaller workgroups; 512^2 x 1: 9.2 us against 9.9 us with 256)
@@ -561,10 +561,10 @@ namespace ocean
     static constexpr int THREADS = 2 * T * PAIRS;
     static constexpr int K = 2;
     static constexpr int PS = 4;
-    static constexpr int LINE = LineFFT<N, PS>::LINE;
+    static constexpr int LINE = LineFFT<N, PS, E>::LINE;
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
     static constexpr bool WALK = (N >= OCEAN_ROW_WALK_FROM) && PAIRS == 1;       // see ocean_rowpass_kernel
-    static constexpr size_t LDS = ((size_t)LineFFT<N>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)4 * T : 0)) * sizeof(cf);      // + the walking variant's twiddle stash
+    static constexpr size_t LDS = ((size_t)LineFFT<N, 4, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)4 * T : 0)) * sizeof(cf);      // + the walking variant's twiddle stash
 
     static constexpr int PER_CU = (LDS * 2 <= (size_t)160 * 1024) ? 2 : 1;                     // persistent workgroups per compute unit (walking)
     static constexpr int MIN_WAVES = WALK ? (THREADS / 64) * PER_CU / 4 : 1;                    // per SIMD, for __launch_bounds__
@@ -591,6 +591,15 @@ namespace ocean
         case 6: return -ca.x;
         default: return R * (ca.y - ca.x);
       }
+    }
+    else if (E == 16)
+    {
+      // sin(alpha + s pi / 8) = sin(alpha) cos(s pi / 8) + cos(alpha) sin(s pi / 8)
+      constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+      constexpr float cs[16] = { 1.0f, C1, R, S1, 0.0f, -S1, -R, -C1, -1.0f, -C1, -R, -S1, 0.0f, S1, R, C1 };
+      constexpr float sn[16] = { 0.0f, S1, R, C1, 1.0f, C1, R, S1, 0.0f, -S1, -R, -C1, -1.0f, -C1, -R, -S1 };
+
+      return fmaf(ca.y, cs[s & 15], ca.x * sn[s & 15]);
     }
     else
     {
@@ -619,15 +628,15 @@ namespace ocean
   template<int N, bool H16>
   __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) ocean_rowpass_kernel(StepArgs a)
   {
-    typedef Plan<N> P;
-    typedef LineFFT<N> L;
     typedef RowCfg<N> C;
+    typedef Plan<N, C::E> P;
+    typedef LineFFT<N, 4, C::E> L;
 
     constexpr int E = P::E;
     constexpr int T = P::T;
     constexpr int K = C::K;
-    static_assert(E == 8 || E == 4, "slot_sine covers E = 4 and 8");
-    static_assert(elem_in<N>(0, 1) == T && elem_out<N>(0, 1) == T, "slots are T columns apart");
+    static_assert(E == 16 || E == 8 || E == 4, "slot_sine covers E = 4, 8 and 16");
+    static_assert(elem_in<N, E>(0, 1) == T && elem_out<N, E>(0, 1) == T, "slots are T columns apart");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -718,8 +727,8 @@ namespace ocean
 
     cf const ca_ = a.tw[t_];                  // exp(2 pi i t / N)
 
-    typename LineTw<N>::type w_;
-    LineTw<N>::load(a.tw, t_, w_);
+    typename LineTw<N, E>::type w_;
+    LineTw<N, E>::load(a.tw, t_, w_);
 
 #ifdef OCEAN_STAMPS
     unsigned long long *stampbase = a.stamps + (size_t)blockIdx.x * 16;
@@ -729,7 +738,7 @@ namespace ocean
 
     constexpr bool WALK = row_walks<N>();
 
-    static_assert(!WALK || 1 + LineTw<N>::type::NMIDREG + P::M <= 4, "twiddle stash");
+    static_assert(!WALK || 1 + LineTw<N, E>::type::NMIDREG + P::M <= 4, "twiddle stash");
 
     cf *twstash = midtab + L::MIDTAB + C::PAIRS * 2 * K * C::LINE;       // [4][T], walking only
 
@@ -740,12 +749,12 @@ namespace ocean
         twstash[t_] = ca_;
 
         #pragma unroll
-        for(int k = 0; k < LineTw<N>::type::NMIDREG; ++k)
+        for(int k = 0; k < LineTw<N, E>::type::NMIDREG; ++k)
           twstash[(1 + k) * T + t_] = w_.mid[k];
 
         #pragma unroll
         for(int m = 0; m < P::M; ++m)
-          twstash[(1 + LineTw<N>::type::NMIDREG + m) * T + t_] = w_.last[m];
+          twstash[(1 + LineTw<N, E>::type::NMIDREG + m) * T + t_] = w_.last[m];
       }
 
       __syncthreads();
@@ -755,7 +764,7 @@ namespace ocean
     {
       int t = t_;
       cf ca = ca_;
-      typename LineTw<N>::type w = w_;
+      typename LineTw<N, E>::type w = w_;
 
       if constexpr (WALK)
       {
@@ -769,12 +778,12 @@ namespace ocean
         ca = twstash[t];
 
         #pragma unroll
-        for(int k = 0; k < LineTw<N>::type::NMIDREG; ++k)
+        for(int k = 0; k < LineTw<N, E>::type::NMIDREG; ++k)
           w.mid[k] = twstash[(1 + k) * T + t];
 
         #pragma unroll
         for(int m = 0; m < P::M; ++m)
-          w.last[m] = twstash[(1 + LineTw<N>::type::NMIDREG + m) * T + t];
+          w.last[m] = twstash[(1 + LineTw<N, E>::type::NMIDREG + m) * T + t];
       }
 
       OCEAN_STAMP(1);
@@ -893,7 +902,7 @@ namespace ocean
       };
 
 #ifndef OCEAN_ABLATE_ROWFFT
-      fft_lines<N, K, C::PS>(v, t, line, C::LINE, midtab, w, true, rest);
+      fft_lines<N, K, C::PS, E>(v, t, line, C::LINE, midtab, w, true, rest);
 #else
       rest();
 #endif
@@ -949,17 +958,17 @@ namespace ocean
   template<int N>
   struct ColCfg
   {
-    static constexpr int E = Plan<N>::E;
-    static constexpr int T = Plan<N>::T;
+#ifndef OCEAN_COL_E16_FROM
+#define OCEAN_COL_E16_FROM 8192    // 16 points per thread (half the threads per column, twice the registers each; 4096 = 16^3 saves an exchange):
+#endif                             // measured at 4096^2 (512-thread tiles of two columns): 170-187 us against a steady 174-175 us with 8: off
+    static constexpr int E = (N >= OCEAN_COL_E16_FROM) ? 16 : default_radix(N);
+    static constexpr int T = Plan<N, E>::T;
 #ifndef OCEAN_COL_THREADS
 #define OCEAN_COL_THREADS 0        // 0 = by size
 #endif
 #ifndef OCEAN_COL_FIELDS
 #define OCEAN_COL_FIELDS 2         // fields per barrier phase: 2 (together) or 1 (one after the other, half the LDS)
 #endif
-    static constexpr int WRAW = ((OCEAN_COL_THREADS != 0) ? OCEAN_COL_THREADS : ((T < 128) ? 256 : (T == 128) ? 512 : 1024)) / T;    // 512^2 x 1: 8.4 us with 256 threads, 10.1 us with 512
-    static constexpr int W = WRAW > 8 ? 8 : (WRAW < 1 ? 1 : WRAW);      // columns per workgroup, one per thread group
-    static constexpr int THREADS = W * T;
     static constexpr int K = OCEAN_COL_FIELDS;
 #ifndef OCEAN_COL_PAD_SHIFT
 #define OCEAN_COL_PAD_SHIFT 3
@@ -968,11 +977,17 @@ namespace ocean
 #define OCEAN_COL_CS_EXTRA 12
 #endif
     static constexpr int PS = OCEAN_COL_PAD_SHIFT;
-    static constexpr int CS = LineFFT<N, PS>::LINE + OCEAN_COL_CS_EXTRA;   // LDS line stride (complex)
+    static constexpr int CS = LineFFT<N, PS, E>::LINE + OCEAN_COL_CS_EXTRA;   // LDS line stride (complex)
+    static constexpr int WRAW = ((OCEAN_COL_THREADS != 0) ? OCEAN_COL_THREADS : ((T < 128) ? 256 : (T == 128) ? 512 : 1024)) / T;    // 512^2 x 1: 8.4 us with 256 threads, 10.1 us with 512
+    static constexpr int WLDS = (int)(((size_t)160 * 1024 - (size_t)LineFFT<N, 4, E>::MIDTAB * sizeof(cf)) / ((size_t)K * CS * sizeof(cf)));   // columns whose lines fit the LDS
+    static constexpr int WFIT = WLDS >= 8 ? 8 : WLDS >= 4 ? 4 : WLDS >= 2 ? 2 : 1;
+    static constexpr int WCAP = WRAW > 8 ? 8 : (WRAW < 1 ? 1 : WRAW);
+    static constexpr int W = WCAP < WFIT ? WCAP : WFIT;                 // columns per workgroup, one per thread group
+    static constexpr int THREADS = W * T;
     static constexpr int SY = N + 64 / W;                                  // height exchange: column stride (floats)
     static constexpr int TILES = N / W;
 
-    static constexpr size_t OFF_MAIN = (size_t)LineFFT<N>::MIDTAB * sizeof(cf);
+    static constexpr size_t OFF_MAIN = (size_t)LineFFT<N, 4, E>::MIDTAB * sizeof(cf);
     static constexpr size_t MAIN_FFT = (size_t)W * K * CS * sizeof(cf);
     static constexpr size_t MAIN_DZ = (size_t)W * SY * sizeof(float);
     static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
@@ -1001,9 +1016,9 @@ namespace ocean
   template<int N, bool H16>
   __global__ void __launch_bounds__(ColCfg<N>::THREADS, OCEAN_COL_MINBLOCKS) ocean_colpass_kernel(StepArgs a)
   {
-    typedef Plan<N> P;
-    typedef LineFFT<N> L;
     typedef ColCfg<N> C;
+    typedef Plan<N, C::E> P;
+    typedef LineFFT<N, 4, C::E> L;
 
     constexpr int E = P::E;
     constexpr int T = P::T;
@@ -1091,8 +1106,8 @@ namespace ocean
     OCEAN_STAMP_WHERE();
     OCEAN_STAMP(0);
 
-    typename LineTw<N>::type w_;
-    LineTw<N>::load(a.tw, t_, w_);
+    typename LineTw<N, E>::type w_;
+    LineTw<N, E>::load(a.tw, t_, w_);
 
     // One tile: `q` holds its values as loaded; when `more`, the next tile's values are requested into `q` again between
     // the last exchange and the last pass (registers are free there) and are in flight during the last pass, the map
@@ -1113,12 +1128,12 @@ namespace ocean
 
       // (the per-thread twiddles stay in registers across tiles: a load issued here would be younger than the previous
       // tile's stores, and waiting for it would wait for them)
-      typename LineTw<N>::type w = w_;
+      typename LineTw<N, E>::type w = w_;
 
       if constexpr (WALK)
       {
         #pragma unroll
-        for(int k = 0; k < LineTw<N>::type::NMIDREG; ++k)
+        for(int k = 0; k < LineTw<N, E>::type::NMIDREG; ++k)
           asm volatile("" : "+v"(w.mid[k].x), "+v"(w.mid[k].y));
 
         #pragma unroll
@@ -1143,7 +1158,7 @@ namespace ocean
 
 #ifndef OCEAN_ABLATE_COLFFT
       if constexpr (K == 2)
-        fft_lines<N, 2, C::PS>(v, t, lines + cp * C::CS, W * C::CS, midtab, w, true, prefetch);    // lines [K][W][CS]: columns CS apart as tuned for bank spread
+        fft_lines<N, 2, C::PS, E>(v, t, lines + cp * C::CS, W * C::CS, midtab, w, true, prefetch);    // lines [K][W][CS]: columns CS apart as tuned for bank spread
       else
       {
         #pragma unroll
@@ -1156,9 +1171,9 @@ namespace ocean
             u[0][s] = v[f][s];
 
           if (f == 1)
-            fft_lines<N, 1, C::PS>(u, t, lines + cp * C::CS, C::CS, midtab, w, true, prefetch);
+            fft_lines<N, 1, C::PS, E>(u, t, lines + cp * C::CS, C::CS, midtab, w, true, prefetch);
           else
-            fft_lines<N, 1, C::PS>(u, t, lines + cp * C::CS, C::CS, midtab, w, true);
+            fft_lines<N, 1, C::PS, E>(u, t, lines + cp * C::CS, C::CS, midtab, w, true);
 
           #pragma unroll
           for(int s = 0; s < E; ++s)

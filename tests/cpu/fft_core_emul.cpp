@@ -8,11 +8,11 @@
 
 using namespace ocean;
 
-template<int N>
+template<int N, int E = default_radix(N)>
 static void run_line(float const *in, float *out)
 {
-  typedef LineFFT<N> L;
-  typedef Plan<N> P;
+  typedef LineFFT<N, 4, E> L;
+  typedef Plan<N, E> P;
 
   std::vector<cf> tw(N);
   for(int k = 0; k < N; ++k)
@@ -79,6 +79,21 @@ extern "C" int emul_line_ifft(int N, float const *in, float *out)
     case 1024: run_line<1024>(in, out); break;
     case 2048: run_line<2048>(in, out); break;
     case 4096: run_line<4096>(in, out); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+// the same with 16 points per thread (the column pass of the largest grids: ColCfg::E)
+extern "C" int emul_line_ifft16(int N, float const *in, float *out)
+{
+  switch(N)
+  {
+    case 256: run_line<256, 16>(in, out); break;
+    case 512: run_line<512, 16>(in, out); break;
+    case 1024: run_line<1024, 16>(in, out); break;
+    case 2048: run_line<2048, 16>(in, out); break;
+    case 4096: run_line<4096, 16>(in, out); break;
     default: return -1;
   }
   return 0;

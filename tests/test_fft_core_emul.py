@@ -45,3 +45,20 @@ def test_line_transform_impulses(emul):
         n = np.arange(N)
         want = np.exp(2j * np.pi * ((k * n) % N) / N)
         assert np.abs((out[:, 0] + 1j * out[:, 1]) - want).max() < 2e-6, k
+
+
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
+def test_line_transform_sixteen_points_per_thread(emul, N):
+    # the plans with radix 16 (4096 = 16^3 is what the column pass of the largest grid runs: ColCfg::E)
+    rng = np.random.default_rng(16 * N)
+    x = rng.standard_normal((N, 2)).astype(np.float32)
+    out = np.empty_like(x)
+    assert emul.emul_line_ifft16(N, x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0
+    _check(out, x, N)
+    for k in (1, 15, 16, 255, N // 2, N - 1):
+        x = np.zeros((N, 2), np.float32)
+        x[k, 0] = 1
+        assert emul.emul_line_ifft16(N, x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0
+        n = np.arange(N)
+        want = np.exp(2j * np.pi * ((k * n) % N) / N)
+        assert np.abs((out[:, 0] + 1j * out[:, 1]) - want).max() < 2e-6, k
