@@ -124,7 +124,14 @@ namespace
       return e;
 
     *what = "hipFuncSetAttribute(ocean_colpass_kernel, MaxDynamicSharedMemorySize)";
-    return hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
+    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
+    if (e != hipSuccess)
+      return e;
+
+    if constexpr (col_has_plain_variant<N>())
+      e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
+
+    return e;
   }
 
   template<int N>
@@ -171,6 +178,12 @@ namespace
   {
     void *args[] = { &a };
     void const *kernel = ctx->half ? reinterpret_cast<void const*>(&ocean_colpass_kernel<N, true>) : reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>);
+
+    if constexpr (col_has_plain_variant<N>())
+    {
+      if (col_plain_maps<N>(ctx->cascades))
+        kernel = ctx->half ? reinterpret_cast<void const*>(&ocean_colpass_kernel<N, true, true>) : reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false, true>);
+    }
 
     // work items = tiles x cascades; the large grids' workgroups are persistent, one per compute unit (the LDS of a
     // 1024-thread tile fills a CU), and walk their share of the items

@@ -1013,7 +1013,15 @@ namespace ocean
   // them 208 -> 187 us and 248 -> 259 us (not every step of this was a gain on its own)
   template<int N, bool H16> constexpr bool col_walks() { return N >= OCEAN_COL_WALK_FROM; }
 
-  template<int N, bool H16>
+  // PLAIN: the maps' stores are not written through (col_plain_maps: the sizes at which several cascades' maps are far
+  // beyond the Infinity Cache although one cascade's are not; the policy is part of the instruction, hence a template flag)
+  template<int N> constexpr bool col_has_plain_variant() { return N == 2048; }
+
+  // 2048^2: one cascade (134 MB of maps) keeps the written-through stores, two or more plain ones (x 2: column pass
+  // 79 -> 75 us, x 4: 167.5 -> 160.8 us; x 1: 36.5 -> 37 us; 1024^2 x 8 / x 16: no difference) -- profiles/r02_4096_second_pass.txt
+  template<int N> inline bool col_plain_maps(int cascades) { return col_has_plain_variant<N>() && cascades >= 2; }
+
+  template<int N, bool H16, bool PLAIN = false>
   __global__ void __launch_bounds__(ColCfg<N>::THREADS, OCEAN_COL_MINBLOCKS) ocean_colpass_kernel(StepArgs a)
   {
     typedef ColCfg<N> C;
@@ -1241,7 +1249,7 @@ namespace ocean
 #ifndef OCEAN_MAP_STORE_AUX_BIG
 #define OCEAN_MAP_STORE_AUX_BIG 0
 #endif
-          constexpr int MAPAUX = (N <= 2048) ? OCEAN_MAP_STORE_AUX : OCEAN_MAP_STORE_AUX_BIG;
+          constexpr int MAPAUX = (N <= 2048 && !PLAIN) ? OCEAN_MAP_STORE_AUX : OCEAN_MAP_STORE_AUX_BIG;
 
 #ifndef OCEAN_COL_LINE_STORES
 #define OCEAN_COL_LINE_STORES 1

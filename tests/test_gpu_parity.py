@@ -325,7 +325,7 @@ def test_cascades_are_independent(capi, oracle):
 # -- properties at BASELINE.json's sizes ------------------------------------------------------------------------
 
 
-@pytest.mark.parametrize("N,cascades", [(1024, 4), (2048, 1), (4096, 1)])
+@pytest.mark.parametrize("N,cascades", [(1024, 4), (2048, 1), (2048, 2), (4096, 1)])     # (2048, 2): the column kernel with plain map stores
 def test_plane_wave_known_answer(capi, oracle, N, cascades):
     # one nonzero h0 bin per cascade -> closed-form two-plane-wave displacement (see tests/test_oracle_pins.py)
     wavescale = 22.0
