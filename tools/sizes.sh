@@ -12,7 +12,8 @@ run --resolution 1024 --cascades 4 --steps 1000 --warmup 100
 run --resolution 512 --cascades 1 --steps 2000 --warmup 200
 run --resolution 1024 --cascades 8 --steps 500 --warmup 50
 run --resolution 2048 --cascades 1 --steps 500 --warmup 50
-run --resolution 2048 --cascades 4 --steps 200 --warmup 20
-run --resolution 4096 --cascades 1 --steps 100 --warmup 10
-run --resolution 4096 --cascades 1 --steps 100 --warmup 10 --spectrum fp16
+run --resolution 2048 --cascades 4 --steps 300 --warmup 30
+run --resolution 1024 --cascades 16 --steps 300 --warmup 30
+run --resolution 4096 --cascades 1 --steps 200 --warmup 20
+run --resolution 4096 --cascades 1 --steps 200 --warmup 20 --spectrum fp16
 run --resolution 1024 --cascades 4 --steps 1000 --warmup 100 --spectrum fp16
