@@ -542,9 +542,6 @@ namespace ocean
 #ifndef OCEAN_ROW_REST_IN_HOOK
 #define OCEAN_ROW_REST_IN_HOOK 1
 #endif
-#ifndef OCEAN_ROW_EARLY_AT
-#define OCEAN_ROW_EARLY_AT 0
-#endif
 #ifndef OCEAN_ROW_EARLY
 #define OCEAN_ROW_EARLY 3          // walking row pass: the parts of the next pair's inputs requested BEFORE the transforms (see request): h0 and its mirror row
 #endif
@@ -615,14 +612,17 @@ namespace ocean
 
   // One group of row pairs per workgroup -- except at N >= OCEAN_ROW_WALK_FROM, where one 1024-thread workgroup fills a CU
   // (LDS) and a pair's phases ran one after the other with 4-5 us between two workgroups on a CU (store drain + launch):
-  // there the workgroups are persistent and walk their pairs; the next pair's inputs are requested behind the transforms,
-  // BEFORE the current pair's stores, so that the wait for them counts past those stores and the stores drain under the next
-  // pair's arithmetic (4096^2: 178 -> 168 us).  What it took to keep hipcc from spilling at the 128 registers a thread may
-  // have there (a spill's reload is a vector-memory load whose wait drains the very stores that should overlap): the request
+  // there the workgroups are persistent and walk their pairs.  The next pair's inputs are requested BEFORE the current
+  // pair's stores, so that the wait for them counts past those stores and the stores drain under the next pair's
+  // arithmetic -- and as early as the 128 registers a thread may have there allow: h0 and its mirror row (32 registers,
+  // OCEAN_ROW_EARLY) before the transforms, phase and dispersion (16) between the last exchange and the last pass, where
+  // the value registers are free (fft_lines' before_last hook).  4096^2: 178 us one pair per workgroup, 161-168 us walking
+  // with everything requested behind the transforms, 135-137 us so; all 48 before the transforms spill (191 us), h0 +
+  // mirror + phase fits and is slower (146-150 us): profiles/r02_4096_second_pass.txt.  What it took to keep hipcc from
+  // spilling (a spill's reload is a vector-memory load whose wait drains the very stores that should overlap): the request
   // is unconditional (the last pair requests itself again: under "if (more)" the old inputs stay live as the other arm of
   // the merge), the thread's twiddles wait in LDS between pairs, and its coordinates are re-derived per pair from an opaque
-  // copy of its index.  Requested earlier, before the transforms, the inputs' 48 registers do not fit (nor, two rows per
-  // thread in 512-thread workgroups, their 96 on top of 209 in 256): profiles/r02_large_grids.txt.
+  // copy of its index.  (Two rows per thread in 512-thread workgroups: 96 registers of inputs on top of 209 in 256.)
   template<int N> constexpr bool row_walks() { return RowCfg<N>::WALK; }
 
   template<int N, bool H16>
@@ -846,9 +846,6 @@ namespace ocean
         swap_out[padidx<C::PS>(t + T * s)] = h[s];
       }
 
-      if constexpr (WALK && OCEAN_ROW_EARLY != 0 && OCEAN_ROW_EARLY_AT == 1)
-        request(next, t, in, OCEAN_ROW_EARLY);
-
       __syncthreads();
 
       OCEAN_STAMP(2);
@@ -891,7 +888,7 @@ namespace ocean
 
       OCEAN_STAMP(3);
 
-      if constexpr (WALK && OCEAN_ROW_EARLY != 0 && OCEAN_ROW_EARLY_AT == 0)
+      if constexpr (WALK && OCEAN_ROW_EARLY != 0)
         request(next, t, in, OCEAN_ROW_EARLY);
 
       // the rest between the last exchange and the last pass, where the value registers are free
