@@ -94,9 +94,54 @@ namespace ocean
 
     return __builtin_bit_cast(cf, r);
   }
+
+  // a + conj(b) = (a.x + b.x, a.y - b.y)
+  __device__ __forceinline__ cf add_conj(cf a, cf b)
+  {
+    v2f_ va = __builtin_bit_cast(v2f_, a), vb = __builtin_bit_cast(v2f_, b), r;
+
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(va), "v"(vb));
+
+    return __builtin_bit_cast(cf, r);
+  }
+
+  // a + c * conj(b) for a real c = (a.x + c b.x, a.y - c b.y)
+  __device__ __forceinline__ cf fma_conj(cf a, cf b, float c)
+  {
+    v2f_ va = __builtin_bit_cast(v2f_, a), vb = __builtin_bit_cast(v2f_, b), vc = { c, c }, r;
+
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[1,0,0]" : "=v"(r) : "v"(vb), "v"(vc), "v"(va));
+
+    return __builtin_bit_cast(cf, r);
+  }
+
+  // a + c * (-i b) for a real c = (a.x + c b.y, a.y - c b.x)
+  __device__ __forceinline__ cf fma_negi(cf a, cf b, float c)
+  {
+    v2f_ va = __builtin_bit_cast(v2f_, a), vb = __builtin_bit_cast(v2f_, b), vc = { c, c }, r;
+
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(vb), "v"(vc), "v"(va));
+
+    return __builtin_bit_cast(cf, r);
+  }
+
+  // c * a for a real c
+  __device__ __forceinline__ cf scale_real(cf a, float c)
+  {
+    v2f_ va = __builtin_bit_cast(v2f_, a), vc = { c, c }, r;
+
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(va), "v"(vc));
+
+    return __builtin_bit_cast(cf, r);
+  }
 #else
   // a * b
   OC_HD cf cmul(cf a, cf b) { return { fmaf_(a.x, b.x, -(a.y * b.y)), fmaf_(a.x, b.y, a.y * b.x) }; }
+
+  OC_HD cf add_conj(cf a, cf b) { return { a.x + b.x, a.y - b.y }; }
+  OC_HD cf fma_conj(cf a, cf b, float c) { return { fmaf_(c, b.x, a.x), fmaf_(-c, b.y, a.y) }; }
+  OC_HD cf fma_negi(cf a, cf b, float c) { return { fmaf_(c, b.y, a.x), fmaf_(-c, b.x, a.y) }; }
+  OC_HD cf scale_real(cf a, float c) { return { c * a.x, c * a.y }; }
 
   OC_HD cf fma_real(cf a, cf b, float h) { return { fmaf_(h, b.x, a.x), fmaf_(h, b.y, a.y) }; }
   OC_HD cf fms_real(cf a, cf b, float h) { return { fmaf_(-h, b.x, a.x), fmaf_(-h, b.y, a.y) }; }

@@ -353,7 +353,7 @@ namespace ocean
     cf const u = cmul(cf{ h0k.x, h0k.y }, e);
     cf const m = cmul(cf{ h0mk.x, h0mk.y }, e);
 
-    return cf{ u.x + m.x, u.y - m.y };
+    return add_conj(u, m);
   }
 
   // 1 / |k| with the bare hardware reciprocal square root (1 ulp; k2 is never denormal on these grids), 0 at k = 0
@@ -558,7 +558,7 @@ namespace ocean
     static constexpr int THREADS = 2 * T * PAIRS;
     static constexpr int K = 2;
     static constexpr int PS = 4;
-    static constexpr int LINE = LineFFT<N, PS, E>::LINE;
+    static constexpr int LINE = LineFFT<N, PS, E>::LINE + 2;               // + element 0 again at index N (the Hermitian swap), kept 16-byte aligned
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
     static constexpr bool WALK = (N >= OCEAN_ROW_WALK_FROM) && PAIRS == 1;       // see ocean_rowpass_kernel
     static constexpr size_t LDS = ((size_t)LineFFT<N, 4, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)4 * T : 0)) * sizeof(cf);      // + the walking variant's twiddle stash
@@ -661,6 +661,7 @@ namespace ocean
     constexpr int DBO = (int)(blocked<N>(0, T) - blocked<N>(0, 0));
 
     static_assert(T % SBC == 0, "slots must be whole blocks apart");
+    static_assert(T % (1 << C::PS) == 0, "slot-to-slot LDS offsets must be constants");
 
     typedef typename SpecValue<H16>::type SV;
 
@@ -846,6 +847,10 @@ namespace ocean
         swap_out[padidx<C::PS>(t + T * s)] = h[s];
       }
 
+      // element 0 once more at index N: the partner of x is N - x for every x, without a wrap
+      if (t == 0)
+        swap_out[padidx<C::PS>(N)] = h[0];
+
       __syncthreads();
 
       OCEAN_STAMP(2);
@@ -863,24 +868,23 @@ namespace ocean
       {
         int const x = t + T * s;
 
-        cf n = swap_in[padidx<C::PS>((N - x) & (N - 1))];
-
-        cf const b = cf{ n.x, -n.y };                                   // conj(h~[-k])
+        // h~ at the negated index N - x (no wrap: element 0 also sits at index N), slot to slot a constant apart
+        cf const n = swap_in[padidx<C::PS>(N - t) - s * (T + (T >> C::PS))];
 
         float const kx = wavevector(x, N, cc.scale);
         float const kinv = kinv_fast(kx, ky);
         float const khx = kx * kinv, khy = ky * kinv;
 
         // TWICE the Hermitian parts (the column pass folds the 1/2 into its sign factor): of h~, and of h~ as it enters hx, hy
-        cf const hh = cf{ h[s].x + b.x, h[s].y + b.y };
-        cf const hhx = (s == 0) ? cf{ fmaf(cx, b.x, hh.x), fmaf(cx, b.y, hh.y) } : hh;
-        cf const hhy = cf{ fmaf(cy, b.x, hh.x), fmaf(cy, b.y, hh.y) };
+        cf const hh = add_conj(h[s], n);                                // h~[k] + conj(h~[-k])
+        cf const hhx = (s == 0) ? fma_conj(hh, n, cx) : hh;
+        cf const hhy = fma_conj(hh, n, cy);
 
         float const s2 = 2.0f * slot_sine<E>(ca, s);                    // 2 sin(2 pi x / N)
 
         // C = h_H + i (-i k^x hhx) = h_H + k^x hhx ;  D = -i k^y hhy + 2 sin(theta) h_H
-        v[0][s] = cf{ fmaf(khx, hhx.x, hh.x), fmaf(khx, hhx.y, hh.y) };
-        v[1][s] = cf{ fmaf(khy, hhy.y, s2 * hh.x), fmaf(-khy, hhy.x, s2 * hh.y) };
+        v[0][s] = fma_real(hh, hhx, khx);
+        v[1][s] = fma_negi(scale_real(hh, s2), hhy, khy);
       }
 
       // every thread has fetched its partner values before pass 0 overwrites the lines
