@@ -837,7 +837,13 @@ int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, 
 
   void *args[] = { &g };
 
-  HIPCHECK(ctx, hipLaunchKernel(reinterpret_cast<void const*>(&ocean_gen_kernel), dim3(g.tiles), dim3(GEN_THREADS), args, GEN_LDS, ctx->stream));
+#if OCEAN_GEN_PIPELINED
+  int const groups = std::min(g.tiles, ctx->cus * OCEAN_GEN_GROUPS_PER_CU);     // persistent: each walks its share of the tiles
+#else
+  int const groups = g.tiles;
+#endif
+
+  HIPCHECK(ctx, hipLaunchKernel(reinterpret_cast<void const*>(&ocean_gen_kernel), dim3(groups), dim3(GEN_THREADS), args, GEN_LDS, ctx->stream));
 
   return DATUM_OCEAN_OK;
 }

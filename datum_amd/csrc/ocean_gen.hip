@@ -116,8 +116,27 @@ namespace ocean
     }
   };
 
-  // One vertex (xx, yy) of data/ocean.gen.comp:67-137.  Writes the vertex as three float4 into `out`.
-  __device__ __forceinline__ void gen_vertex(GenArgs const &g, GlobalMap const &map, int xx, int yy, float4 (&out)[3])
+  // One vertex (xx, yy) of data/ocean.gen.comp:67-137 in three stages, so that the kernel can put another vertex's
+  // arithmetic between the fetches of one and their use:
+  //   gen_ray    view ray, plane hit, Gerstner swell position, distance smoothing, bilinear corners and weights (gen.comp:75-112)
+  //   gen_fetch  the (up to) eight texel fetches (gen.comp:113-114)
+  //   gen_shade  bilinear blend, shading frame, the vertex as three float4 (gen.comp:113-137)
+  struct GenRay
+  {
+    f3 position;
+    float w00, w10, w01, w11;       // bilinear weights
+    int t00, t10, t01, t11;         // float4 index of the corners' displacement texels (map_index)
+    float smoothing;
+    float st, ct;                   // swell phase
+  };
+
+  struct GenTexels
+  {
+    float4 a00, a10, a01, a11;      // displacement layer
+    float4 b00, b10, b01, b11;      // normal layer
+  };
+
+  __device__ __forceinline__ void gen_ray(GenArgs const &g, int xx, int yy, GenRay &ray)
   {
 #ifdef OCEAN_STAMPS
     unsigned long long *stampbase = g.stamps + (size_t)blockIdx.x * 16;
@@ -153,7 +172,7 @@ namespace ocean
     // Gerstner swell (gen.comp:93-109)
     float const amplitude = p.swellamplitude;
     float const dirx = p.swelldirection[0], diry = p.swelldirection[1];
-    float const qi = f.qi, phi = f.phi;
+    float const qi = f.qi;
 
     float theta = f.frequency * (dirx * baseposition.x + diry * baseposition.y) + p.swellphase;
 
@@ -202,29 +221,54 @@ namespace ocean
 
     static_assert(MAP_GROUP == 4, "a group is one 128-byte line: 8 float4");
 
-    bool const shaded = smoothing != 1.0f;       // otherwise the sampled normal is multiplied by an exact 0
-
-    float4 const zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-
-    float4 a00 = zero, a10 = zero, a01 = zero, a11 = zero;
-    float4 b00 = zero, b10 = zero, b01 = zero, b11 = zero;
+    ray.position = position;
+    ray.w00 = w00; ray.w10 = w10; ray.w01 = w01; ray.w11 = w11;
+    ray.t00 = r0 + c0; ray.t10 = r0 + c1; ray.t01 = r1 + c0; ray.t11 = r1 + c1;
+    ray.smoothing = smoothing;
+    ray.st = st; ray.ct = ct;
 
     OCEAN_STAMP(1);
+  }
+
+  __device__ __forceinline__ void gen_fetch(GlobalMap const &map, GenRay const &ray, GenTexels &t)
+  {
+    bool const shaded = ray.smoothing != 1.0f;       // otherwise the sampled normal is multiplied by an exact 0
 
 #ifdef OCEAN_GEN_ABLATE_LOADS      // timing-only builds (tools/): no map fetches
-    a00 = a10 = a01 = a11 = make_float4(0.01f * (float)(i0 & 7), 0.02f, 0.03f * (float)(j0 & 3), 0.0f);
-    b00 = b10 = b01 = b11 = make_float4(0.0f, 0.1f, 0.9f, 0.0f);
+    t.a00 = t.a10 = t.a01 = t.a11 = make_float4(0.01f * (float)(ray.t00 & 7), 0.02f, 0.03f * (float)(ray.t01 & 3), 0.0f);
+    t.b00 = t.b10 = t.b01 = t.b11 = make_float4(0.0f, 0.1f, 0.9f, 0.0f);
 #else
     // all eight fetches are issued back to back and waited for once (a fetch inside a branch is waited for where the
     // branch rejoins: four round trips to the Infinity Cache per vertex, measured)
-    map.fetch(r0 + c0, w00 != 0.0f, shaded, a00, b00);
-    map.fetch(r0 + c1, w10 != 0.0f, shaded, a10, b10);
-    map.fetch(r1 + c0, w01 != 0.0f, shaded, a01, b01);
-    map.fetch(r1 + c1, w11 != 0.0f, shaded, a11, b11);
+    map.fetch(ray.t00, ray.w00 != 0.0f, shaded, t.a00, t.b00);
+    map.fetch(ray.t10, ray.w10 != 0.0f, shaded, t.a10, t.b10);
+    map.fetch(ray.t01, ray.w01 != 0.0f, shaded, t.a01, t.b01);
+    map.fetch(ray.t11, ray.w11 != 0.0f, shaded, t.a11, t.b11);
 #endif
+  }
 
+  __device__ __forceinline__ void gen_shade(GenArgs const &g, GenRay const &ray, GenTexels const &t, float4 (&out)[3])
+  {
+#ifdef OCEAN_STAMPS
+    unsigned long long *stampbase = g.stamps + (size_t)blockIdx.x * 16;
+#endif
     OCEAN_WAIT_LOADS();
     OCEAN_STAMP(2);
+
+    datum_ocean_set const &p = g.set;
+    GenFrame const &f = g.frame;
+
+    f3 const planen = { p.plane[0], p.plane[1], p.plane[2] };
+    float const dirx = p.swelldirection[0], diry = p.swelldirection[1];
+    float const qi = f.qi, phi = f.phi;
+
+    f3 const position = ray.position;
+    float const w00 = ray.w00, w10 = ray.w10, w01 = ray.w01, w11 = ray.w11;
+    float const smoothing = ray.smoothing, st = ray.st, ct = ray.ct;
+    bool const shaded = smoothing != 1.0f;
+
+    float4 const a00 = t.a00, a10 = t.a10, a01 = t.a01, a11 = t.a11;
+    float4 const b00 = t.b00, b10 = t.b10, b01 = t.b01, b11 = t.b11;
 
     // (the sums below the base position are contracted into FMAs: the shading frame and the bilinear blend do not feed
     // an ill-conditioned step, and ocean.gen's tolerance is stated separately from the maps')
@@ -275,6 +319,16 @@ namespace ocean
     out[2] = make_float4(tbn0.x, tbn0.y, tbn0.z, -1.0f);
   }
 
+  __device__ __forceinline__ void gen_vertex(GenArgs const &g, GlobalMap const &map, int xx, int yy, float4 (&out)[3])
+  {
+    GenRay ray;
+    GenTexels texels;
+
+    gen_ray(g, xx, yy, ray);
+    gen_fetch(map, ray, texels);
+    gen_shade(g, ray, texels, out);
+  }
+
   // The wave's 4 rows x 16 vertices = 4 x 48 float4 go through its 3 KB of LDS: thread i then stores float4 number
   // i, 64 + i, 128 + i of the wave's 192 (three 16-byte stores per thread at a 48-byte stride touched every line three
   // times: 26 -> 21 us per 1024^2 mesh from 64^2 maps).
@@ -310,8 +364,21 @@ namespace ocean
 
   }
 
-  // One tile per workgroup, tiles in row-major order.
-  // (68 VGPRs = 7 workgroups per CU; forced to 64 for 8: 18.7 against 17.7 us)
+#ifndef OCEAN_GEN_PIPELINED
+#define OCEAN_GEN_PIPELINED 0
+#endif
+#ifndef OCEAN_GEN_GROUPS_PER_CU
+#define OCEAN_GEN_GROUPS_PER_CU 5
+#endif
+
+  // One tile per workgroup, tiles in row-major order (68 VGPRs = 7 workgroups per CU; forced to 64 for 8: 18.7 against 17.7 us).
+  //
+  // OCEAN_GEN_PIPELINED (measured, off): persistent workgroups walk the tiles (workgroup b takes tiles b, b + gridDim.x, ...)
+  // and put the ray and swell arithmetic of the NEXT tile's vertex between the fetches of the current one and their use
+  // (the request after the last tile repeats it: no branch around loads, see GlobalMap).  96 VGPRs, five workgroups per
+  // CU: 35.7-37.3 us against 34.3 us from 1024^2 maps, 20.1-20.8 against 18.1 us from 64^2 maps, with 3 / 4 / 5 / 6 / 8
+  // workgroups per CU alike; every second workgroup starting 3.4 us late in the one-tile kernel: + 2.5-4.5 us
+  // (profiles/r02_gen_experiments.txt).
   __global__ void __launch_bounds__(GEN_THREADS) ocean_gen_kernel(GenArgs g)
   {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -322,12 +389,44 @@ namespace ocean
 
     GlobalMap const map = { make_rsrc(g.map, (size_t)2 * g.N * g.N * sizeof(float4)) };
 
+#if OCEAN_GEN_PIPELINED
+    int const stride = (int)gridDim.x;
+    int tile = (int)blockIdx.x;
+
+    GenRay ray;
+    GenTexels texels;
+
+    gen_ray(g, (tile % g.tilesx) * GEN_TILE + (tid & 15), (tile / g.tilesx) * GEN_TILE + (tid >> 4), ray);
+    gen_fetch(map, ray, texels);
+
+    for(; tile < g.tiles; tile += stride)
+    {
+      int const next = (tile + stride < g.tiles) ? tile + stride : tile;
+
+      GenRay ahead;
+      gen_ray(g, (next % g.tilesx) * GEN_TILE + (tid & 15), (next / g.tilesx) * GEN_TILE + (tid >> 4), ahead);
+
+      // hipcc otherwise sinks this arithmetic below the shading (nothing there depends on it) and the fetches are waited
+      // for as soon as they are issued: pin `ahead` here and keep the scheduler from moving anything across
+      asm volatile("" :: "v"(ahead.position.x), "v"(ahead.position.y), "v"(ahead.position.z), "v"(ahead.w00), "v"(ahead.w10), "v"(ahead.w01), "v"(ahead.w11),
+                         "v"(ahead.t00), "v"(ahead.t10), "v"(ahead.t01), "v"(ahead.t11), "v"(ahead.smoothing), "v"(ahead.st), "v"(ahead.ct));
+      __builtin_amdgcn_sched_barrier(0);
+
+      float4 vtx[3];
+      gen_shade(g, ray, texels, vtx);
+      gen_store_tile(g, stage, tile % g.tilesx, tile / g.tilesx, tid, vtx);
+
+      ray = ahead;
+      gen_fetch(map, ray, texels);
+    }
+#else
     int const tile = (int)blockIdx.x;
     int const tilex = tile % g.tilesx, tiley = tile / g.tilesx;
 
     float4 vtx[3];
     gen_vertex(g, map, tilex * GEN_TILE + (tid & 15), tiley * GEN_TILE + (tid >> 4), vtx);
     gen_store_tile(g, stage, tilex, tiley, tid, vtx);
+#endif
 
 #ifdef OCEAN_STAMPS
     unsigned long long *stampbase = g.stamps + (size_t)blockIdx.x * 16;
