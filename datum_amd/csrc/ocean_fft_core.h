@@ -413,9 +413,20 @@ namespace ocean
 
       if (PASS == 1)
       {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(OCEAN_TWIDDLE_SHFL)
+        // experiment (north_star's wording, "twiddles broadcast by wave64 __shfl"): lane l of every wave holds table entry
+        // l (E * E <= 64 entries) and the E - 1 factors of a thread come from other lanes' registers (ds_bpermute)
+        // instead of from the LDS table.  Measured on this build: profiles/r02_twiddle_shfl.txt
+        cf const mine = midtab[(threadIdx.x & 63) % (E * E)];
+
+        OC_UNROLL
+        for(int r = 1; r < E; ++r)
+          v[r] = cmul(v[r], cf{ __shfl(mine.x, r * E + (t % E)), __shfl(mine.y, r * E + (t % E)) });
+#else
         OC_UNROLL
         for(int r = 1; r < E; ++r)
           v[r] = cmul(v[r], midtab[r * E + (t % E)]);
+#endif
       }
       else
       {
