@@ -177,7 +177,10 @@ namespace ocean
 #endif
 
   // points per thread of a line transform unless the caller chooses (the kernels do, per pass: RowCfg / ColCfg)
-  constexpr int default_radix(int n) { return n == 64 ? 4 : OCEAN_FFT_E; }
+#ifndef OCEAN_FFT_E16_FROM
+#define OCEAN_FFT_E16_FROM (1 << 30)      // experiments: 16 points per thread from this resolution up, in both passes
+#endif
+  constexpr int default_radix(int n) { return n == 64 ? 4 : (n >= OCEAN_FFT_E16_FROM ? 16 : OCEAN_FFT_E); }
 
   template<int N, int E_ = default_radix(N)>
   struct Plan

@@ -959,10 +959,17 @@ namespace ocean
   template<int N>
   struct ColCfg
   {
+    // 16 points per thread at 1024^2 (1024 = 16 x 16 x 4: three passes, two exchanges, 256-thread tiles of four columns),
+    // with the two fields one after the other (half the LDS: 37 KB, three workgroups per CU at 148 registers): column pass
+    // 34.2 -> 31.3 us, 65.8 k -> 69 k grids/s (tools/ab_4096.sh, profiles/r02_col_radix16.txt).  Not elsewhere: 512^2 8.2
+    // against 5.5 us, 2048^2 x 4 168 against 160 us, 4096^2 170-187 (erratic) against 174-175 us.
 #ifndef OCEAN_COL_E16_FROM
-#define OCEAN_COL_E16_FROM 8192    // 16 points per thread (half the threads per column, twice the registers each; 4096 = 16^3 saves an exchange):
-#endif                             // measured at 4096^2 (512-thread tiles of two columns): 170-187 us against a steady 174-175 us with 8: off
-    static constexpr int E = (N >= OCEAN_COL_E16_FROM) ? 16 : default_radix(N);
+#define OCEAN_COL_E16_FROM 1024
+#endif
+#ifndef OCEAN_COL_E16_TO
+#define OCEAN_COL_E16_TO 2048
+#endif
+    static constexpr int E = (N >= OCEAN_COL_E16_FROM && N < OCEAN_COL_E16_TO) ? 16 : default_radix(N);
     static constexpr int T = Plan<N, E>::T;
 #ifndef OCEAN_COL_THREADS
 #define OCEAN_COL_THREADS 0        // 0 = by size
@@ -970,7 +977,10 @@ namespace ocean
 #ifndef OCEAN_COL_FIELDS
 #define OCEAN_COL_FIELDS 2         // fields per barrier phase: 2 (together) or 1 (one after the other, half the LDS)
 #endif
-    static constexpr int K = OCEAN_COL_FIELDS;
+#ifndef OCEAN_COL_FIELDS_E16
+#define OCEAN_COL_FIELDS_E16 1
+#endif
+    static constexpr int K = (E == 16) ? OCEAN_COL_FIELDS_E16 : OCEAN_COL_FIELDS;
 #ifndef OCEAN_COL_PAD_SHIFT
 #define OCEAN_COL_PAD_SHIFT 3
 #endif
