@@ -215,12 +215,14 @@ def camera(fov, aspect, znear, zfar, position, target, up):
     return s
 
 
-def example_oceanset(N, params=None, swellphase=0.0):
-    """OceanSet header for the example-ocean camera (examples/ocean/ocean.cpp:33,63; ocean.h:17-18)."""
+def oceanset(N, position=(0, 0, 8), target=(1, 0, 8), up=(0, 0, 1), params=None, swellphase=0.0,
+             fov=60.0 * np.pi / 180.0, aspect=1920.0 / 1080.0, znear=0.1, zfar=24000.0):
+    """OceanSet header (src/renderer/ocean.cpp:729-746) for a lookat camera and EXAMPLE overridden by `params`.
+    The defaults are the example-ocean camera (examples/ocean/ocean.cpp:33,63; ocean.h:17-18)."""
     p = dict(EXAMPLE)
     if params:
         p.update(params)
-    s = camera(60.0 * np.pi / 180.0, 1920.0 / 1080.0, 0.1, 24000.0, (0, 0, 8), (1, 0, 8), (0, 0, 1))
+    s = camera(fov, aspect, znear, zfar, position, target, up)
     s.plane[:] = p["plane"]
     s.swelllength = p["swelllength"]
     s.swellamplitude = p["swellamplitude"]
@@ -232,6 +234,11 @@ def example_oceanset(N, params=None, swellphase=0.0):
     s.smoothing = np.float32(1.0) / np.float32(p["smoothing"])
     s.size = N
     return s
+
+
+def example_oceanset(N, params=None, swellphase=0.0):
+    """OceanSet header for the example-ocean camera (examples/ocean/ocean.cpp:33,63; ocean.h:17-18)."""
+    return oceanset(N, params=params, swellphase=swellphase)
 
 
 def gen(oceanset, displacementmap, sizex, sizey):

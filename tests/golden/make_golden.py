@@ -14,7 +14,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
 from oracle import oracle as o  # noqa: E402
+import gen_cases  # noqa: E402
 
 N = 64
 SEED = 1000
@@ -40,6 +43,10 @@ def main():
     s = o.example_oceanset(N, swellphase=0.25)
     out["vertices_600_32x32"] = o.gen(s, out["maps_600"], 32, 32)
     out["oceanset"] = np.frombuffer(bytes(s), np.uint8).copy()
+    # a steep swell seen from a camera pitched 30 degrees down: every qi * ... term of gen.comp:97-105 is non-zero
+    steep = gen_cases.oceanset(o, N, "pitched_steep", swellphase=1.9)
+    out["vertices_600_steep_48x40"] = o.gen(steep, out["maps_600"], 48, 40)
+    out["oceanset_steep"] = np.frombuffer(bytes(steep), np.uint8).copy()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ocean_n64.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path))

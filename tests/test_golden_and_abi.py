@@ -36,6 +36,13 @@ def test_oracle_reproduces_golden(oracle, golden):
     assert bytes(s) == golden["oceanset"].tobytes()
     v = oracle.gen(s, golden["maps_600"], 32, 32)
     assert np.allclose(v, golden["vertices_600_32x32"], rtol=0, atol=1e-6)
+    import gen_cases
+
+    steep = gen_cases.oceanset(oracle, N, "pitched_steep", swellphase=1.9)
+    assert steep.swellsteepness > 0.5
+    assert bytes(steep) == golden["oceanset_steep"].tobytes()
+    v = oracle.gen(steep, golden["maps_600"], 48, 40)
+    assert np.allclose(v, golden["vertices_600_steep_48x40"], rtol=0, atol=1e-6)
 
 
 def test_fused_update_equals_separate(oracle, golden):

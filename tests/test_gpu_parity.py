@@ -433,6 +433,155 @@ def test_gen_vertices(capi, oracle, torch, N, size):
     assert np.all(got[..., 11] == -1)
 
 
+def _gen_setup(capi, oracle, N, cascades=1, seeds=(1000,), wavescales=(22.0,), steps=10):
+    p = oracle.EXAMPLE
+    oc = capi.Ocean(N, cascades)
+    for c in range(cascades):
+        oc.set_cascade(c, wavescales[c], p["choppiness"])
+        oc.upload_state(c, make_state(oracle, N, seeds[c], wavescales[c]))
+    for _ in range(steps):
+        oc.update(DT)
+    oc.displace()
+    return oc
+
+
+def _gen_check(oracle, report, label, s, got, maps, sx, sy):
+    """got against the oracle's ocean.gen on the same maps at the stated bars (every vertex), and -- for the record --
+    both against the float64 restatement of gen.comp on the vertices where fp32 determines the answer at all."""
+    import gen_cases
+
+    want = oracle.gen(s, maps, sx, sy)
+    assert np.isfinite(got).all()
+    pos, tex, frame = gen_cases.compare(got, want)
+    f64, dist, costheta = gen_cases.gen_f64(s, maps, sx, sy)
+    ok = gen_cases.well_conditioned(s, dist, costheta)
+    hp, _, hf = gen_cases.compare(got[ok], f64[ok])
+    op, _, of = gen_cases.compare(want[ok], f64[ok])
+    report(f"gen {label}: N={maps.shape[1]} mesh {sx}x{sy}: HIP vs oracle pos {pos:.2e} tex {tex:.2e} frame {frame:.2e} (bars 2e-4); "
+           f"rays hitting the plane {(costheta > 0).mean():.2f}, well-conditioned {ok.mean():.2f}: vs float64 HIP pos {hp:.2e} frame {hf:.2e}, "
+           f"oracle pos {op:.2e} frame {of:.2e}; identical floats {(got == want).mean():.3f}")
+    assert pos < 2e-4, label
+    assert tex < 2e-4, label
+    assert frame < 2e-4, label
+    assert np.all(got[..., 11] == -1)
+    assert hp < 2e-4 and hf < 2e-4
+    return want
+
+
+GEN_CASES = ["example", "pitched_steep", "above_horizon", "rolled", "high", "plane_w"]
+
+
+@pytest.mark.parametrize("case", GEN_CASES)
+def test_gen_cameras_and_swell(capi, oracle, torch, report, case):
+    # gen.comp:93-120 with every qi * ... term non-zero (steepness 0.3 / 0.8), pitched / rolled / high cameras, rays above
+    # the horizon, plane.w != 0, swell directions off the default; the mesh is ragged in both directions
+    import gen_cases
+
+    N, sx, sy = 256, 200, 150
+    s = gen_cases.oceanset(oracle, N, case)
+    hs = capi.OceanSet.from_buffer_copy(bytes(s))
+    if case != "example":
+        assert s.swellsteepness > 0
+    verts = torch.full((sx * sy * 12 + 64,), 12345.0, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    with _gen_setup(capi, oracle, N) as oc:
+        oc.gen(0, hs, sx, sy, verts.data_ptr())
+        oc.sync()
+        maps = oc.read_maps(0)
+    raw = verts.cpu().numpy()
+    assert np.all(raw[sx * sy * 12:] == 12345.0)
+    got = raw[: sx * sy * 12].reshape(sy, sx, 12)
+    want = _gen_check(oracle, report, case, s, got, maps, sx, sy)
+    # the steep cases really exercise the horizontal Gerstner offset: position.xy moves by up to qi * amplitude
+    if s.swellsteepness > 0:
+        flat = gen_cases.oceanset(oracle, N, case)
+        flat.swellsteepness = 0.0
+        assert np.abs(oracle.gen(flat, maps, sx, sy)[..., 0:2] - want[..., 0:2]).max() > 0.05
+
+
+@pytest.mark.parametrize("case,N,size", [("pitched_steep", 1024, 1024), ("rolled", 1024, 1024), ("above_horizon", 64, 1024),
+                                         ("plane_w", 2048, 224), ("high", 4096, 160)])
+def test_gen_cases_at_bench_shapes(capi, oracle, torch, report, case, N, size):
+    # the bench shape (1024^2 maps and 64^2 maps, 1024^2 mesh) and the banded / patched map layouts under the new cameras
+    import gen_cases
+
+    s = gen_cases.oceanset(oracle, N, case, swellphase=2.1)
+    hs = capi.OceanSet.from_buffer_copy(bytes(s))
+    verts = torch.zeros(size * size * 12, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    with _gen_setup(capi, oracle, N, steps=3) as oc:
+        oc.gen(0, hs, size, size, verts.data_ptr())
+        oc.sync()
+        maps = oc.read_maps(0)
+    _gen_check(oracle, report, f"{case}/bench", s, verts.cpu().numpy().reshape(size, size, 12), maps, size, size)
+
+
+def test_gen_on_a_later_cascade(capi, oracle, torch, report):
+    # datum_ocean_gen(cascade = 2) of a 4-cascade handle samples that cascade's maps (its own wave scale in the header)
+    import gen_cases
+
+    N, sx, sy = 256, 128, 96
+    ws = oracle.CASCADE_WAVESCALES
+    verts = torch.zeros(sx * sy * 12, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    with _gen_setup(capi, oracle, N, 4, (1000, 1001, 1002, 1003), ws) as oc:
+        for c in (2, 3):
+            s = gen_cases.oceanset(oracle, N, "rolled", wavescale=ws[c])
+            oc.gen(c, capi.OceanSet.from_buffer_copy(bytes(s)), sx, sy, verts.data_ptr())
+            oc.sync()
+            maps = oc.read_maps(c)
+            assert not np.array_equal(maps, oc.read_maps(0))
+            _gen_check(oracle, report, f"rolled/cascade{c}", s, verts.cpu().numpy().reshape(sy, sx, 12), maps, sx, sy)
+
+
+@pytest.mark.parametrize("N,wavescale", [(4096, 1.5), (1024, 0.25)])
+def test_gen_texel_coordinates_beyond_int32(capi, oracle, torch, report, N, wavescale):
+    # rays above the horizon land at dist = 1e6 (gen.comp:89): texel coordinate 1e6 / wavescale * N >= 2^31 here.  The
+    # oracle wraps floor(coordinate) modulo N in 64-bit integers; the kernel must pick the same texel (an int32
+    # conversion would saturate and always read texel N - 1).
+    import gen_cases
+
+    sx, sy = 96, 64
+    s = gen_cases.oceanset(oracle, N, "above_horizon", wavescale=wavescale)
+    assert 1e6 * s.scale * N > 2.0 ** 31
+    verts = torch.zeros(sx * sy * 12, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    with _gen_setup(capi, oracle, N, wavescales=(wavescale,), steps=2) as oc:
+        oc.gen(0, capi.OceanSet.from_buffer_copy(bytes(s)), sx, sy, verts.data_ptr())
+        oc.sync()
+        maps = oc.read_maps(0)
+    got = verts.cpu().numpy().reshape(sy, sx, 12)
+    want = _gen_check(oracle, report, f"above_horizon/2^31 N={N}", s, got, maps, sx, sy)
+    far = np.abs(want[..., 0]) * s.scale * N > 2.0 ** 31
+    assert far.mean() > 0.3
+    # the displacement really is sampled there (not a constant texel): z varies over the far vertices as the oracle's does
+    assert np.abs(got[far][:, 2] - want[far][:, 2]).max() < 2e-4
+    assert np.unique(want[far][:, 2]).size > 16
+
+
+def test_gen_golden_steep_vertices(capi, oracle, torch):
+    # committed fixture: N = 64, 600 steps, steep swell seen from a pitched camera (tests/golden/make_golden.py)
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ocean_n64.npz"))
+    p = oracle.EXAMPLE
+    sx, sy = 48, 40
+    want = g["vertices_600_steep_48x40"]
+    hs = capi.OceanSet.from_buffer_copy(g["oceanset_steep"].tobytes())
+    verts = torch.zeros(sx * sy * 12, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    with capi.Ocean(64, 1) as oc:
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        oc.upload_state(0, g["h0"], g["phase_600"])
+        oc.displace()
+        oc.gen(0, hs, sx, sy, verts.data_ptr())
+        oc.sync()
+    import gen_cases
+
+    pos, tex, frame = gen_cases.compare(verts.cpu().numpy().reshape(sy, sx, 12), want)
+    assert pos < 2e-4 and tex < 2e-4 and frame < 2e-4
+
+
 # -- error behaviour -----------------------------------------------------------------------------------------
 
 
