@@ -826,24 +826,11 @@ int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, 
 
   GenArgs g;
   g.set = *set;
-  g.frame = make_gen_frame(*set);
   g.map = ctx->maps + (size_t)cascade * 2 * plane(ctx);
-  g.N = ctx->N;
-  g.sizex = sizex;
-  g.sizey = sizey;
-  g.tilesx = (sizex + GEN_TILE - 1) / GEN_TILE;
-  g.tiles = g.tilesx * ((sizey + GEN_TILE - 1) / GEN_TILE);
   g.vertices = (float*)vertices_device;
+  gen_shape(g, ctx->N, sizex, sizey);
 
-  void *args[] = { &g };
-
-#if OCEAN_GEN_PIPELINED
-  int const groups = std::min(g.tiles, ctx->cus * OCEAN_GEN_GROUPS_PER_CU);     // persistent: each walks its share of the tiles
-#else
-  int const groups = g.tiles;
-#endif
-
-  HIPCHECK(ctx, hipLaunchKernel(reinterpret_cast<void const*>(&ocean_gen_kernel), dim3(groups), dim3(GEN_THREADS), args, GEN_LDS, ctx->stream));
+  HIPCHECK(ctx, launch_gen(g, ctx->stream));
 
   return DATUM_OCEAN_OK;
 }

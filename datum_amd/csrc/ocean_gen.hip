@@ -1,19 +1,34 @@
 // ocean_gen.hip -- ocean.gen (data/ocean.gen.comp:67-137): the projected-grid mesh from the displacement map.
 //
-// One thread per mesh vertex, 16 x 16 vertices per tile.  What the reference does with two texture() fetches of a
-// sampler2DArray (gen.comp:113-114) is a manual bilinear REPEAT fetch from the module's own map layout
-// (ocean_kernels.hip: map_index), in fp32 with float weights (lavapipe-style exact bilinear).  Per vertex:
-//   * a corner whose bilinear weight is exactly 0 is not fetched (0 * finite = 0 adds nothing): beyond |coordinate| =
-//     2^23 texels -- every ray above the horizon, where dist = 1e6 -- the fractional parts vanish and one corner is left;
-//   * the normal layer is not fetched where the distance smoothing (gen.comp:116) is exactly 1: the blended normal is
-//     then the plane's (0 * finite + n), which is the whole upper half of the projected grid and the horizon band;
-//   * the eight fetches of a vertex are buffer loads issued back to back; an unwanted corner's offset is pushed out of
-//     the buffer's range (zeros come back without a memory access), so no branch -- and no wait -- separates them.
-// (Measured and not kept, profiles/r02_gen_experiments.txt: maps of N <= 64 copied into LDS by persistent 512-thread
-// workgroups -- 22 us against 18.5 us, one workgroup per CU cannot hide the arithmetic's latencies; a persistent loop over
-// the tiles -- no gain and 100 instead of 68 VGPRs; alternating workgroups between the top and the bottom of the mesh --
-// 2 us slower.)
-// The 48-byte Mesh::Vertex'es of a wave go through LDS so that every store instruction writes 16 contiguous bytes per lane.
+// The kernel is bound by the vector ALU (profiles/r02_gen_experiments.txt: 419 instructions per vertex, the units busy
+// for 11 of 18 us), so it is built around gfx950's PACKED fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32:
+// two floats per lane per issue): every thread owns TWO vertices of a mesh row, 16 columns apart, and carries them
+// through the shader as the two halves of 64-bit register pairs (`v2`).  What cannot be packed (reciprocals, square roots,
+// exp / log, floor, conversions, the texel addressing, the fetches) is issued per vertex.
+//
+//   * the view ray, the plane hit and the swell phase (gen.comp:81-99) keep the shader's operation order with IEEE-exact
+//     results -- near the horizon the plane hit amplifies one ulp of the ray by dist / costheta and the swell phase turns
+//     metres into radians, so the oracle is only reproducible there with the same roundings.  Exact does not mean the
+//     compiler's division sequence: the operands are in the normal range, so the range scaling and the fix-up are left
+//     out, and the reciprocal of a shared denominator (|viewvec|) is refined once (div_exact, sqrt_exact: the same
+//     refinement steps as the IEEE expansion, packed);
+//   * what does not depend on the vertex is evaluated once on the host in the shader's operation order (GenFrame) --
+//     gfx950 has no scalar float unit, a uniform product costs a vector instruction in every wave;
+//   * the shading frame (gen.comp:101-120) uses v_rsq_f32 / v_exp_f32 / v_log_f32 and FMAs: errors are not amplified there;
+//   * sin / cos of the swell phase (up to 1e5..1e6 at the horizon) by the two-constant Cody-Waite step of sincos_phase;
+//   * texture(sampler2DArray) (gen.comp:113-114) is a manual bilinear REPEAT fetch from the module's own map layout
+//     (ocean_kernels.hip: map_index) in fp32 with float weights (lavapipe-style exact bilinear).  The texel index wraps
+//     through v_fract_f32 of coordinate / N (exact: N is a power of two), right for every float the oracle's 64-bit wrap
+//     is right for -- an int32 conversion saturates from |coordinate| = 2^31 (dist = 1e6 at wavescale < 2, N = 4096);
+//   * where a bilinear weight is exactly 0 along an axis (beyond |coordinate| = 2^23 texels, i.e. every ray above the
+//     horizon) the second texel of that axis is not fetched: its offset is pushed out of the buffer's range (zeros come
+//     back without a memory access), so no branch -- and no wait -- separates the fetches;
+//   * the normal layer is fetched only by waves with a vertex whose distance smoothing (gen.comp:116) is not exactly 1
+//     (elsewhere the blended normal is 0 * finite + plane normal), the Gerstner frame likewise;
+//   * the 48-byte Mesh::Vertex'es of a wave (4 rows x 32 vertices) go through LDS so that every store instruction writes 16
+//     contiguous bytes per lane, 1.5 KB per mesh row.
+// Measured and not kept (profiles/r02_gen_experiments.txt): maps of N <= 64 copied into LDS, a persistent loop over the
+// tiles with the next tile's ray arithmetic under the current tile's fetches, alternating tile order, priority classes.
 
 #pragma once
 
@@ -21,8 +36,10 @@
 
 namespace ocean
 {
-  // per-launch constants of ocean.gen that do not depend on the vertex (gen.comp:75-79,93-99), evaluated once on the
-  // host in the shader's operation order instead of once per thread (gfx950 has no scalar float unit)
+  typedef float v2 __attribute__((ext_vector_type(2)));      // one value of a thread's two vertices
+
+  // per-launch constants of ocean.gen that do not depend on the vertex (gen.comp:75-79,93-105), evaluated once on the
+  // host in the shader's operation order instead of once per thread
   struct GenFrame
   {
     float camerapos[3];
@@ -31,6 +48,15 @@ namespace ocean
     float frequency;
     float qi;
     float phi;
+    float sxm1, sym1;        // float(sizex - 1), float(sizey - 1)
+    float viewz[3];          // invproj[2] * 0.0, [6] * 0.0, [10] * 0.0   (the third term of each viewvec row, gen.comp:84)
+    float vieww[3];          // invproj[3] * 1.0, [7] * 1.0, [11] * 1.0
+    float negplane[3];       // -plane.xyz
+    float basez;             // -plane.w
+    float gx, gy;            // (qi * amplitude) * direction   (gen.comp:101)
+    float nx, ny, nz;        // Gerstner normal  = (nx ct, ny ct, nz st)   (gen.comp:103)
+    float tx, ty, tz;        // Gerstner tangent = (tx st, ty st, tz ct)   (gen.comp:104)
+    float fn, rfn;           // float(N), 1 / float(N)
   };
 
   struct GenArgs
@@ -43,36 +69,24 @@ namespace ocean
     int sizey;
     int tilesx;
     int tiles;
+    int chunk;             // tiles per XCD chunk, 0: tiles in launch order
     float *vertices;
 #ifdef OCEAN_STAMPS
     unsigned long long *stamps;   // diagnostic builds only (tools/dbg/genstamps.hip): [workgroup][16] timestamps
 #endif
   };
 
-  struct f3 { float x, y, z; };
+#ifndef OCEAN_GEN_XCD_CHUNK
+#define OCEAN_GEN_XCD_CHUNK 1        // maps beyond an XCD's L2: chunks of n tile rows are dealt to the XCDs in turn (0: never)
+#endif
 
-  __host__ __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
-  __host__ __device__ __forceinline__ f3 operator*(float s, f3 a) { return { s * a.x, s * a.y, s * a.z }; }
-  __host__ __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-  __host__ __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+  // a workgroup's tile is 32 x 16 vertices, a wave owns 32 x 4 of them (a "wave tile"), a thread (x, y) and (x + 16, y)
+  constexpr int GEN_TILE_X = 32;
+  constexpr int GEN_TILE_Y = 16;
+  constexpr int GEN_THREADS = 256;
+  constexpr size_t GEN_LDS = (size_t)GEN_THREADS * 2 * 3 * sizeof(float4);
 
-  // a / |a|: IEEE square root and divisions, as the oracle does it -- for the view ray, whose direction decides where a
-  // grazing ray meets the plane (one ulp there moves horizon vertices by whole texels)
-  __device__ __forceinline__ f3 normalize3_exact(f3 a) { float l = sqrtf(dot3(a, a)); return { a.x / l, a.y / l, a.z / l }; }
-
-  // a / |a| with the hardware reciprocal square root (1 ulp): the shading frame, where errors are not amplified
-  __device__ __forceinline__ f3 normalize3(f3 a) { float inv = __builtin_amdgcn_rsqf(dot3(a, a)); return { a.x * inv, a.y * inv, a.z * inv }; }
-
-  // rotate v by the unit quaternion q = (w, x, y, z)   (data/transform.inc:32-37)
-  __device__ __forceinline__ f3 rotate(float const (&q)[4], f3 v)
-  {
-    f3 u = { q[1], q[2], q[3] };
-    f3 tt = 2.0f * cross3(u, v);
-
-    return v + q[0] * tt + cross3(u, tt);
-  }
-
-  inline GenFrame make_gen_frame(datum_ocean_set const &p)
+  inline GenFrame make_gen_frame(datum_ocean_set const &p, int N, int sizex, int sizey)
   {
     GenFrame f;
 
@@ -87,57 +101,184 @@ namespace ocean
     f.cameraheight = (p.plane[0] * f.camerapos[0] + p.plane[1] * f.camerapos[1] + p.plane[2] * f.camerapos[2]) + p.plane[3];
     f.margin = 1 + sqrtf((2 * p.swellamplitude + 0.5f) / f.cameraheight);
 
-    // Gerstner swell constants (gen.comp:93-99)
+    f.sxm1 = (float)(sizex - 1);
+    f.sym1 = (float)(sizey - 1);
+
+    for(int r = 0; r < 3; ++r)
+    {
+      f.viewz[r] = p.invproj[4 * r + 2] * 0.0f;
+      f.vieww[r] = p.invproj[4 * r + 3] * 1.0f;
+      f.negplane[r] = -p.plane[r];
+    }
+
+    f.basez = -p.plane[3];
+
+    // Gerstner swell constants (gen.comp:93-105)
     f.frequency = 2 * 3.14159265358979323846f / p.swelllength;
     f.qi = p.swellsteepness / (f.frequency * p.swellamplitude * 4 + 1e-6f);
     f.phi = f.frequency * p.swellamplitude;
 
+    float const dirx = p.swelldirection[0], diry = p.swelldirection[1];
+
+    f.gx = f.qi * p.swellamplitude * dirx;
+    f.gy = f.qi * p.swellamplitude * diry;
+
+    f.nx = f.phi * dirx / 6;
+    f.ny = f.phi * diry / 6;
+    f.nz = f.qi * f.phi;
+    f.tx = f.qi * f.phi * dirx * dirx;
+    f.ty = f.qi * f.phi * diry * dirx;
+    f.tz = f.phi * dirx / 6;
+
+    f.fn = (float)N;
+    f.rfn = 1.0f / (float)N;
+
     return f;
   }
 
-  constexpr int GEN_TILE = 16;                  // vertices per tile side
-  constexpr int GEN_THREADS = GEN_TILE * GEN_TILE;
-  constexpr size_t GEN_LDS = (size_t)GEN_THREADS * 3 * sizeof(float4);
+  //|---------------------- packed helpers --------------------------------------
 
-  // Where a bilinear corner comes from.  `want` = the corner's weight is not zero, `shaded` = the normal layer matters.
-  //
-  // Global map: buffer loads whose offset is pushed out of the buffer's range for a corner that is not wanted -- the
-  // hardware then returns zeros without a memory access, and no branch (hence no wait) separates the fetches.
-  struct GlobalMap
+  struct p3 { v2 x, y, z; };                      // a 3-vector of each of the two vertices
+
+  __device__ __forceinline__ v2 splat(float a) { return v2{ a, a }; }
+  __device__ __forceinline__ v2 pfma(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
+  __device__ __forceinline__ v2 pfma(float a, v2 b, v2 c) { return __builtin_elementwise_fma(splat(a), b, c); }
+  __device__ __forceinline__ v2 pfma(v2 a, v2 b, float c) { return __builtin_elementwise_fma(a, b, splat(c)); }
+  __device__ __forceinline__ v2 pfma(float a, v2 b, float c) { return __builtin_elementwise_fma(splat(a), b, splat(c)); }
+  __device__ __forceinline__ v2 prcp(v2 a) { return v2{ __builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y) }; }
+  __device__ __forceinline__ v2 prsq(v2 a) { return v2{ __builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y) }; }
+  __device__ __forceinline__ v2 pfloor(v2 a) { return v2{ __builtin_floorf(a.x), __builtin_floorf(a.y) }; }
+
+  // (with -ffp-contract=off a product and a sum stay v_pk_mul_f32 + v_pk_add_f32: two IEEE roundings, the oracle's)
+  __device__ __forceinline__ v2 dot3(p3 a, p3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+  // IEEE-exact a / b for operands in the normal range: the refinement steps of the compiler's own fp32 division
+  // (v_rcp_f32, two Newton steps on the reciprocal, quotient + two residual corrections) without v_div_scale / v_div_fixup.
+  // `y` is the refined reciprocal of b: shared by the three components of a normalisation.
+  __device__ __forceinline__ v2 refined_rcp(v2 b)
   {
-    __amdgpu_buffer_rsrc_t rsrc;
+    v2 y = prcp(b);
+    v2 e = pfma(-b, y, 1.0f);
 
-    __device__ __forceinline__ void fetch(int texel, bool want, bool shaded, float4 &a, float4 &b) const
+    return pfma(e, y, y);
+  }
+
+  __device__ __forceinline__ v2 div_exact(v2 a, v2 b, v2 y)
+  {
+    v2 q = a * y;
+    v2 r = pfma(-b, q, a);
+    q = pfma(r, y, q);
+    r = pfma(-b, q, a);
+
+    return pfma(r, y, q);
+  }
+
+  __device__ __forceinline__ v2 div_exact(v2 a, v2 b) { return div_exact(a, b, refined_rcp(b)); }
+
+  // IEEE-exact sqrt(a) for a in the normal range: v_rsq_f32 and the Goldschmidt steps of the compiler's fp32 square root
+  __device__ __forceinline__ v2 sqrt_exact(v2 a)
+  {
+    v2 rs = prsq(a);
+    v2 s = a * rs;
+    v2 h = rs * 0.5f;
+    v2 e = pfma(-h, s, 0.5f);
+
+    h = pfma(h, e, h);
+    s = pfma(s, e, s);
+
+    v2 d = pfma(-s, s, a);
+
+    return pfma(d, h, s);
+  }
+
+  // a / |a| with the hardware reciprocal square root (1 ulp): the shading frame, where errors are not amplified
+  __device__ __forceinline__ p3 normalize3(p3 a)
+  {
+    v2 inv = prsq(pfma(a.z, a.z, pfma(a.y, a.y, a.x * a.x)));
+
+    return { a.x * inv, a.y * inv, a.z * inv };
+  }
+
+  // sincos_phase (ocean_kernels.hip) of two arguments: the same reduction and polynomials, packed
+  __device__ __forceinline__ void sincos_phase2(v2 x, v2 &sn, v2 &cs)
+  {
+    v2 t = x * 0.636619772367581343f;                            // x * 2/pi
+    v2 k = { __builtin_rintf(t.x), __builtin_rintf(t.y) };
+
+    v2 r = pfma(k, splat(-1.57079637050628662109375f), x);       // pi/2 head
+    r = pfma(k, splat(4.37113900018624283e-8f), r);              // pi/2 tail
+
+    v2 z = r * r;
+
+    v2 sp = pfma(pfma(pfma(splat(-1.9515295891e-4f), z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    v2 cp = pfma(pfma(pfma(splat(2.443315711809948e-5f), z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, pfma(z, splat(-0.5f), 1.0f));
+
+    #pragma unroll
+    for(int i = 0; i < 2; ++i)
     {
-      int const off = texel * 16;
+      int q = (int)k[i];
 
-      a = buf_load_f32x4_aux<0>(rsrc, want ? off : -16, 0);
-      b = buf_load_f32x4_aux<0>(rsrc, (want && shaded) ? off + MAP_GROUP * 16 : -16, 0);
+      float s = (q & 1) ? cp[i] : sp[i];
+      float c = (q & 1) ? sp[i] : cp[i];
+
+      sn[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) ^ (((unsigned)q << 30) & 0x80000000u));
+      cs[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c) ^ (((unsigned)(q + 1) << 30) & 0x80000000u));
+    }
+  }
+
+  // rotate v by the unit quaternion q = (w, x, y, z)   (data/transform.inc:32-37), the shader's operation order
+  __device__ __forceinline__ p3 rotate(float const (&q)[4], p3 v)
+  {
+    float const ux = q[1], uy = q[2], uz = q[3];
+
+    p3 tt = { 2.0f * (uy * v.z - uz * v.y), 2.0f * (uz * v.x - ux * v.z), 2.0f * (ux * v.y - uy * v.x) };
+
+    return { (v.x + q[0] * tt.x) + (uy * tt.z - uz * tt.y), (v.y + q[0] * tt.y) + (uz * tt.x - ux * tt.z), (v.z + q[0] * tt.z) + (ux * tt.y - uy * tt.x) };
+  }
+
+  // Float4 index of a texel column's / row's part of map_index (ocean_kernels.hip); the two add up to the texel of layer 0.
+  //   PLAIN   N <= 1024: whole rows, groups of 4 x 1 texels          index = y * 2N + (x & ~3) * 2 + (x & 3)
+  //   BANDED  2048: bands of band_cols(N) columns, 4 x 1 groups
+  //   PATCHED 4096: bands, groups of 2 x 2 texels
+  enum GenLayout { GEN_PLAIN = 0, GEN_BANDED = 1, GEN_PATCHED = 2 };
+
+  template<int LAYOUT> struct TexelIndex
+  {
+    int ln, lb, bmask;
+
+    __device__ __forceinline__ TexelIndex(int N) : ln(31 - __builtin_clz(N)), lb(31 - __builtin_clz(band_cols(N))), bmask(band_cols(N) - 1) { }
+
+    __device__ __forceinline__ int column(int i) const
+    {
+      if constexpr (LAYOUT == GEN_PLAIN)
+        return i + (i & ~3);
+      else if constexpr (LAYOUT == GEN_BANDED)
+        return ((i >> lb) << (1 + ln + lb)) + ((i & bmask) & ~3) * 2 + (i & 3);
+      else
+        return ((i >> lb) << (1 + ln + lb)) + ((i & bmask) & ~1) * 4 + (i & 1);
+    }
+
+    __device__ __forceinline__ int row(int j) const
+    {
+      if constexpr (LAYOUT == GEN_PATCHED)
+        return ((j >> 1) << (2 + lb)) + ((j & 1) << 1);
+      else
+        return j << (1 + lb);
     }
   };
 
-  // One vertex (xx, yy) of data/ocean.gen.comp:67-137 in three stages, so that the kernel can put another vertex's
-  // arithmetic between the fetches of one and their use:
-  //   gen_ray    view ray, plane hit, Gerstner swell position, distance smoothing, bilinear corners and weights (gen.comp:75-112)
-  //   gen_fetch  the (up to) eight texel fetches (gen.comp:113-114)
-  //   gen_shade  bilinear blend, shading frame, the vertex as three float4 (gen.comp:113-137)
-  struct GenRay
-  {
-    f3 position;
-    float w00, w10, w01, w11;       // bilinear weights
-    int t00, t10, t01, t11;         // float4 index of the corners' displacement texels (map_index)
-    float smoothing;
-    float st, ct;                   // swell phase
-  };
+  static_assert(MAP_GROUP == 4, "a group is one 128-byte line: 8 float4");
 
-  struct GenTexels
-  {
-    float4 a00, a10, a01, a11;      // displacement layer
-    float4 b00, b10, b01, b11;      // normal layer
-  };
+  //|---------------------- the kernel ------------------------------------------
+  // (One function, local arrays: with the three stages as functions over structs, or inside a loop over tiles, hipcc keeps
+  // 134-154 registers instead of 86 and spills -- measured 17.7 against 16.3 us; a persistent loop, 3 or 4 workgroups
+  // per CU: 17.1 / 18.1 us; a 1024-thread workgroup per CU sampling a 64^2 map from LDS: 24.5 us.  profiles/r03_gen_experiments.txt)
 
-  __device__ __forceinline__ void gen_ray(GenArgs const &g, int xx, int yy, GenRay &ray)
+  template<int LAYOUT>
+  __global__ void __launch_bounds__(GEN_THREADS) ocean_gen_kernel(GenArgs g)
   {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
 #ifdef OCEAN_STAMPS
     unsigned long long *stampbase = g.stamps + (size_t)blockIdx.x * 16;
 #endif
@@ -146,292 +287,284 @@ namespace ocean
     datum_ocean_set const &p = g.set;
     GenFrame const &f = g.frame;
 
-    int const N = g.N;
+    int const tid = threadIdx.x;
+    int const lane = tid & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    f3 const camerapos = { f.camerapos[0], f.camerapos[1], f.camerapos[2] };
-    f3 const planen = { p.plane[0], p.plane[1], p.plane[2] };
+    // Workgroup b runs on XCD b % 8.  A map that does not fit an XCD's 4 MB L2 is sampled in chunks of whole tile rows
+    // dealt to the XCDs in turn: neighbouring tiles share an L2 (1024^2 maps: 36.4 -> 31.0 us), and every XCD gets its
+    // share of the cheap rows above the horizon (one contiguous run of tiles per XCD: 43 us).  Small maps sit in every
+    // L2 anyway; there the launch order is kept (64^2 maps: 16.5 against 17.1 us).
+    int tile = (int)blockIdx.x;
 
-    // exactly the shader's expressions up to the base position: near the horizon the plane hit is ill-conditioned
-    float u = (2 * (float)xx / (float)(g.sizex - 1) - 1) * f.margin;
-    float v = (1 - 2 * (float)yy / (float)(g.sizey - 1)) * f.margin;
+    if (g.chunk)
+    {
+      int const slot = tile >> 3;
+
+      tile = ((slot / g.chunk) * 8 + (tile & 7)) * g.chunk + slot % g.chunk;
+
+      if (tile >= g.tiles)
+        return;
+    }
+
+    int const tilex = tile % g.tilesx, tiley = tile / g.tilesx;
+
+    int const x0 = tilex * GEN_TILE_X;
+    int const y0 = tiley * GEN_TILE_Y + 4 * wave;                  // first of this wave's four rows
+
+    int const xa = x0 + (lane & 15);
+    int const yy = y0 + (lane >> 4);
+
+    //-- view ray, plane hit, swell phase: the shader's expressions and roundings (gen.comp:81-99) ----------------
+
+    v2 const xx = { (float)xa, (float)(xa + 16) };
+
+    v2 const u = (div_exact(2.0f * xx, splat(f.sxm1)) - 1.0f) * f.margin;
+
+    // (one row per thread: its v is the first half of a packed division whose second half repeats it)
+    float const v = ((1.0f - div_exact(splat(2.0f * (float)yy), splat(f.sym1))) * f.margin).x;
 
     float const *ip = p.invproj;
 
-    f3 viewvec = { ip[0] * u + ip[1] * v + ip[2] * 0.0f + ip[3] * 1.0f,
-                   ip[4] * u + ip[5] * v + ip[6] * 0.0f + ip[7] * 1.0f,
-                   ip[8] * u + ip[9] * v + ip[10] * 0.0f + ip[11] * 1.0f };
+    p3 viewvec = { ((ip[0] * u + ip[1] * v) + f.viewz[0]) + f.vieww[0],
+                   ((ip[4] * u + ip[5] * v) + f.viewz[1]) + f.vieww[1],
+                   ((ip[8] * u + ip[9] * v) + f.viewz[2]) + f.vieww[2] };
 
-    f3 worlddir = rotate(p.camera_real, normalize3_exact(viewvec));
+    v2 const len = sqrt_exact(dot3(viewvec, viewvec));
+    v2 const rlen = refined_rcp(len);
 
-    float costheta = dot3(worlddir, f3{ -planen.x, -planen.y, -planen.z });
+    p3 const worlddir = rotate(p.camera_real, p3{ div_exact(viewvec.x, len, rlen), div_exact(viewvec.y, len, rlen), div_exact(viewvec.z, len, rlen) });
 
-    float dist = (costheta > 0) ? f.cameraheight / costheta : 1e6f;
+    v2 const costheta = worlddir.x * f.negplane[0] + worlddir.y * f.negplane[1] + worlddir.z * f.negplane[2];
 
-    f3 baseposition = { camerapos.x + dist * worlddir.x, camerapos.y + dist * worlddir.y, -p.plane[3] };
+    v2 const hit = div_exact(splat(f.cameraheight), costheta);
 
-    // Gerstner swell (gen.comp:93-109)
-    float const amplitude = p.swellamplitude;
-    float const dirx = p.swelldirection[0], diry = p.swelldirection[1];
-    float const qi = f.qi;
+    v2 const dist = { (costheta.x > 0) ? hit.x : 1e6f, (costheta.y > 0) ? hit.y : 1e6f };
 
-    float theta = f.frequency * (dirx * baseposition.x + diry * baseposition.y) + p.swellphase;
+    v2 const basex = f.camerapos[0] + dist * worlddir.x;
+    v2 const basey = f.camerapos[1] + dist * worlddir.y;
 
-    // theta reaches 1e5..1e6 at the horizon.  The two-constant Cody-Waite step of sincos_phase rounds once, relative to
-    // the REDUCED argument (the products k * c are exact inside the FMAs), and what it leaves out is k * 1e-15: good to
-    // 1e-7 absolute up to |theta| ~ 1e7, without libm's Payne-Hanek branch.
-    float st, ct;
-    sincos_phase(theta, &st, &ct);
+    v2 const theta = f.frequency * (p.swelldirection[0] * basex + p.swelldirection[1] * basey) + p.swellphase;
 
-    f3 position = { baseposition.x + qi * amplitude * dirx * ct, baseposition.y + qi * amplitude * diry * ct, baseposition.z + amplitude * st };
+    v2 st, ct;
+    sincos_phase2(theta, st, ct);
 
-    float cl = dist * p.smoothing - 0.35f;
-    cl = fminf(fmaxf(cl, 0.0f), 1.0f);
-    float smoothing = __builtin_amdgcn_exp2f(0.2f * __builtin_amdgcn_logf(cl));   // pow(cl, 0.2): 0 -> 0, 1 -> 1 exactly
+    p3 const position = { basex + f.gx * ct, basey + f.gy * ct, f.basez + p.swellamplitude * st };
 
-    // texture(sampler2DArray, REPEAT, linear, lod 0) of both layers at normalised (tu, tv): texel centres at (i + 0.5) / N.
-    // N is a power of two: REPEAT is a mask (two's complement makes it right for negative texel indices too).
-    float tu = position.x * p.scale;
-    float tv = position.y * p.scale;
+    v2 cl = dist * p.smoothing - 0.35f;
 
-    float fx = tu * (float)N - 0.5f;
-    float fy = tv * (float)N - 0.5f;
+    v2 smoothing;       // pow(clamp(cl, 0, 1), 0.2): 0 -> 0, 1 -> 1 exactly
 
-    float flx = floorf(fx);
-    float fly = floorf(fy);
+    #pragma unroll
+    for(int i = 0; i < 2; ++i)
+      smoothing[i] = __builtin_amdgcn_exp2f(0.2f * __builtin_amdgcn_logf(__builtin_amdgcn_fmed3f(cl[i], 0.0f, 1.0f)));
 
-    float ax = fx - flx;
-    float ay = fy - fly;
+    //-- texture(sampler2DArray, REPEAT, linear, lod 0) of both layers at (position.xy * scale): texel centres at (i + 0.5) / N ----
 
-    int i0 = (int)flx & (N - 1);
-    int j0 = (int)fly & (N - 1);
-    int i1 = (i0 + 1) & (N - 1);
-    int j1 = (j0 + 1) & (N - 1);
+    v2 const fx = (position.x * p.scale) * f.fn - 0.5f;
+    v2 const fy = (position.y * p.scale) * f.fn - 0.5f;
 
-    float const w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
+    v2 const flx = pfloor(fx), fly = pfloor(fy);
 
-    // map_index, rows and columns apart (large maps are stored in bands of columns; groups of GX x GY texels).  Every
-    // extent is a power of two: shifts by wave-uniform amounts (divisions by run-time values cost some 30 instructions each)
-    int const lb = 31 - __builtin_clz(band_cols(N)), ln = 31 - __builtin_clz(N);
-    int const lgx = 31 - __builtin_clz(map_group_cols(N)), lgy = 31 - __builtin_clz(map_group_rows(N));
-    int const bmask = (1 << lb) - 1, xmask = (1 << lgx) - 1, ymask = (1 << lgy) - 1;
+    v2 const ax = fx - flx, ay = fy - fly;
 
-    int const r0 = ((j0 >> lgy) << (1 + lgy + lb)) + ((j0 & ymask) << lgx), r1 = ((j1 >> lgy) << (1 + lgy + lb)) + ((j1 & ymask) << lgx);
-    int const c0 = ((i0 >> lb) << (1 + ln + lb)) + (((i0 & bmask) >> lgx) << 3) + (i0 & xmask);
-    int const c1 = ((i1 >> lb) << (1 + ln + lb)) + (((i1 & bmask) >> lgx) << 3) + (i1 & xmask);
+    // floor(coordinate) mod N: N is a power of two, so coordinate / N, its fractional part and the product with N are exact
+    v2 const wx = flx * f.rfn, wy = fly * f.rfn;
+    v2 const mx = v2{ __builtin_amdgcn_fractf(wx.x), __builtin_amdgcn_fractf(wx.y) } * f.fn;
+    v2 const my = v2{ __builtin_amdgcn_fractf(wy.x), __builtin_amdgcn_fractf(wy.y) } * f.fn;
 
-    static_assert(MAP_GROUP == 4, "a group is one 128-byte line: 8 float4");
+    v2 const bx = 1.0f - ax, by = 1.0f - ay;
+    v2 const w00 = bx * by, w10 = ax * by, w01 = bx * ay, w11 = ax * ay;
 
-    ray.position = position;
-    ray.w00 = w00; ray.w10 = w10; ray.w01 = w01; ray.w11 = w11;
-    ray.t00 = r0 + c0; ray.t10 = r0 + c1; ray.t01 = r1 + c0; ray.t11 = r1 + c1;
-    ray.smoothing = smoothing;
-    ray.st = st; ray.ct = ct;
+    TexelIndex<LAYOUT> const texel(g.N);
+
+    int const nmask = g.N - 1;
+
+    int o00[2], o10[2], o01[2], o11[2];       // byte offsets of the four corners' displacement texels
+
+    #pragma unroll
+    for(int i = 0; i < 2; ++i)
+    {
+      int const i0 = (int)mx[i], j0 = (int)my[i];
+
+      int const i1 = (i0 + 1) & nmask, j1 = (j0 + 1) & nmask;
+
+      int const c0 = texel.column(i0) * 16, c1 = texel.column(i1) * 16;
+      int const r0 = texel.row(j0) * 16, r1 = texel.row(j1) * 16;
+
+      // A zero weight along an axis (beyond |coordinate| = 2^23 texels: every ray above the horizon): the second texel of
+      // that axis is not needed (0 * finite adds nothing).  Its offset is pushed out of the buffer's range: zeros come
+      // back without a memory access, and no branch -- hence no wait -- separates the fetches.
+      bool const wantx = ax[i] != 0.0f, wanty = ay[i] != 0.0f;
+
+      o00[i] = r0 + c0; o10[i] = wantx ? r0 + c1 : -256; o01[i] = wanty ? r1 + c0 : -256; o11[i] = (wantx && wanty) ? r1 + c1 : -256;
+    }
 
     OCEAN_STAMP(1);
-  }
 
-  __device__ __forceinline__ void gen_fetch(GlobalMap const &map, GenRay const &ray, GenTexels &t)
-  {
-    bool const shaded = ray.smoothing != 1.0f;       // otherwise the sampled normal is multiplied by an exact 0
+    __amdgpu_buffer_rsrc_t const rmap = make_rsrc(g.map, (size_t)2 * g.N * g.N * sizeof(float4));
+
+    // wave-uniform: only a wave with a vertex inside the smoothing distance needs the normal layer and the Gerstner frame
+    bool const shaded = __builtin_amdgcn_ballot_w64(smoothing.x != 1.0f || smoothing.y != 1.0f) != 0;
+
+    float4 a00[2], a10[2], a01[2], a11[2];      // displacement layer
+    float4 b00[2], b10[2], b01[2], b11[2];      // normal layer
 
 #ifdef OCEAN_GEN_ABLATE_LOADS      // timing-only builds (tools/): no map fetches
-    t.a00 = t.a10 = t.a01 = t.a11 = make_float4(0.01f * (float)(ray.t00 & 7), 0.02f, 0.03f * (float)(ray.t01 & 3), 0.0f);
-    t.b00 = t.b10 = t.b01 = t.b11 = make_float4(0.0f, 0.1f, 0.9f, 0.0f);
+    #pragma unroll
+    for(int i = 0; i < 2; ++i)
+    {
+      a00[i] = a10[i] = a01[i] = a11[i] = make_float4(0.01f * (float)(o00[i] & 7), 0.02f, 0.03f * (float)(o01[i] & 3), 0.0f);
+      b00[i] = b10[i] = b01[i] = b11[i] = make_float4(0.0f, 0.1f, 0.9f, 0.0f);
+    }
 #else
-    // all eight fetches are issued back to back and waited for once (a fetch inside a branch is waited for where the
-    // branch rejoins: four round trips to the Infinity Cache per vertex, measured)
-    map.fetch(ray.t00, ray.w00 != 0.0f, shaded, t.a00, t.b00);
-    map.fetch(ray.t10, ray.w10 != 0.0f, shaded, t.a10, t.b10);
-    map.fetch(ray.t01, ray.w01 != 0.0f, shaded, t.a01, t.b01);
-    map.fetch(ray.t11, ray.w11 != 0.0f, shaded, t.a11, t.b11);
-#endif
-  }
+    // (a corner's normal sits in the 128-byte line of its displacement: fetched right behind it, it finds the line in L1 --
+    // eight displacement fetches of 64 lanes later the line may have left the cache again)
+    #define OCEAN_GEN_FETCH_A(C) a##C[i] = buf_load_f32x4_aux<0>(rmap, o##C[i], 0)
+    #define OCEAN_GEN_FETCH_B(C) b##C[i] = buf_load_f32x4_aux<0>(rmap, o##C[i] + MAP_GROUP * 16, 0)
 
-  __device__ __forceinline__ void gen_shade(GenArgs const &g, GenRay const &ray, GenTexels const &t, float4 (&out)[3])
-  {
-#ifdef OCEAN_STAMPS
-    unsigned long long *stampbase = g.stamps + (size_t)blockIdx.x * 16;
+    if (shaded)
+    {
+      #pragma unroll
+      for(int i = 0; i < 2; ++i)
+      {
+        OCEAN_GEN_FETCH_A(00); OCEAN_GEN_FETCH_B(00);
+        OCEAN_GEN_FETCH_A(10); OCEAN_GEN_FETCH_B(10);
+        OCEAN_GEN_FETCH_A(01); OCEAN_GEN_FETCH_B(01);
+        OCEAN_GEN_FETCH_A(11); OCEAN_GEN_FETCH_B(11);
+      }
+    }
+    else
+    {
+      #pragma unroll
+      for(int i = 0; i < 2; ++i)
+      {
+        OCEAN_GEN_FETCH_A(00);
+        OCEAN_GEN_FETCH_A(10);
+        OCEAN_GEN_FETCH_A(01);
+        OCEAN_GEN_FETCH_A(11);
+      }
+    }
+
+    #undef OCEAN_GEN_FETCH_A
+    #undef OCEAN_GEN_FETCH_B
 #endif
+
     OCEAN_WAIT_LOADS();
     OCEAN_STAMP(2);
 
-    datum_ocean_set const &p = g.set;
-    GenFrame const &f = g.frame;
+    //-- bilinear blend and shading frame (gen.comp:101-120), FMAs ------------------------------------------------
 
-    f3 const planen = { p.plane[0], p.plane[1], p.plane[2] };
-    float const dirx = p.swelldirection[0], diry = p.swelldirection[1];
-    float const qi = f.qi, phi = f.phi;
+    #define OCEAN_GEN_BLEND(T, C) pfma(w11, v2{ T##11[0].C, T##11[1].C }, pfma(w01, v2{ T##01[0].C, T##01[1].C }, pfma(w10, v2{ T##10[0].C, T##10[1].C }, w00 * v2{ T##00[0].C, T##00[1].C })))
 
-    f3 const position = ray.position;
-    float const w00 = ray.w00, w10 = ray.w10, w01 = ray.w01, w11 = ray.w11;
-    float const smoothing = ray.smoothing, st = ray.st, ct = ray.ct;
-    bool const shaded = smoothing != 1.0f;
+    p3 const displacement = { OCEAN_GEN_BLEND(a, x), OCEAN_GEN_BLEND(a, y), OCEAN_GEN_BLEND(a, z) };
 
-    float4 const a00 = t.a00, a10 = t.a10, a01 = t.a01, a11 = t.a11;
-    float4 const b00 = t.b00, b10 = t.b10, b01 = t.b01, b11 = t.b11;
+    p3 const planen = { splat(p.plane[0]), splat(p.plane[1]), splat(p.plane[2]) };
 
-    // (the sums below the base position are contracted into FMAs: the shading frame and the bilinear blend do not feed
-    // an ill-conditioned step, and ocean.gen's tolerance is stated separately from the maps')
-    f3 const displacement = { fmaf(w11, a11.x, fmaf(w01, a01.x, fmaf(w10, a10.x, w00 * a00.x))),
-                              fmaf(w11, a11.y, fmaf(w01, a01.y, fmaf(w10, a10.y, w00 * a00.y))),
-                              fmaf(w11, a11.z, fmaf(w01, a01.z, fmaf(w10, a10.z, w00 * a00.z))) };
+    p3 tbn2;
 
-    f3 tbn2, tbn0;
-
-    // wave-uniform: a wave whose vertices all lie beyond the smoothing distance (the upper half of the projected grid
-    // and the horizon band) skips the Gerstner frame and the normal blend: with smoothing == 1 the blend below is
-    // 0 * tn + planen = planen exactly
-    if (__builtin_amdgcn_ballot_w64(shaded) != 0)
+    if (shaded)
     {
-      float const sixth = 1.0f / 6;
+      p3 const dn = { OCEAN_GEN_BLEND(b, x), OCEAN_GEN_BLEND(b, y), OCEAN_GEN_BLEND(b, z) };
 
-      f3 normal = { phi * dirx * ct * sixth, phi * diry * ct * sixth, qi * phi * st };
-      f3 tangent = { qi * phi * dirx * dirx * st, qi * phi * diry * dirx * st, phi * dirx * ct * sixth };
+      // tbn[2] = normalize(-normal.xy, 1 - normal.z), tbn[0] = normalize(1 - tangent.x, -tangent.y, tangent.z), tbn[1] = tbn[0] x tbn[2]
+      p3 const t2 = normalize3(p3{ -f.nx * ct, -f.ny * ct, pfma(-f.nz, st, 1.0f) });
+      p3 const t0 = normalize3(p3{ pfma(-f.tx, st, 1.0f), -f.ty * st, f.tz * ct });
+      p3 const t1 = { t0.y * t2.z - t0.z * t2.y, t0.z * t2.x - t0.x * t2.z, t0.x * t2.y - t0.y * t2.x };
 
-      tbn2 = normalize3(f3{ -normal.x, -normal.y, 1 - normal.z });
-      tbn0 = normalize3(f3{ 1 - tangent.x, -tangent.y, tangent.z });
+      // tbn * displacementnormal, mixed towards the plane normal with the distance smoothing
+      p3 const tn = { pfma(dn.z, t2.x, pfma(dn.y, t1.x, dn.x * t0.x)), pfma(dn.z, t2.y, pfma(dn.y, t1.y, dn.x * t0.y)), pfma(dn.z, t2.z, pfma(dn.y, t1.z, dn.x * t0.z)) };
 
-      f3 tbn1 = cross3(tbn0, tbn2);
+      v2 const keep = 1.0f - smoothing;
 
-      f3 const dn = { fmaf(w11, b11.x, fmaf(w01, b01.x, fmaf(w10, b10.x, w00 * b00.x))),
-                      fmaf(w11, b11.y, fmaf(w01, b01.y, fmaf(w10, b10.y, w00 * b00.y))),
-                      fmaf(w11, b11.z, fmaf(w01, b01.z, fmaf(w10, b10.z, w00 * b00.z))) };
-
-      f3 tn = { fmaf(dn.z, tbn2.x, fmaf(dn.y, tbn1.x, dn.x * tbn0.x)),
-                fmaf(dn.z, tbn2.y, fmaf(dn.y, tbn1.y, dn.x * tbn0.y)),
-                fmaf(dn.z, tbn2.z, fmaf(dn.y, tbn1.z, dn.x * tbn0.z)) };
-
-      float const keep = 1 - smoothing;
-
-      tbn2 = normalize3(f3{ fmaf(keep, tn.x, smoothing * planen.x), fmaf(keep, tn.y, smoothing * planen.y), fmaf(keep, tn.z, smoothing * planen.z) });
+      tbn2 = normalize3(p3{ pfma(keep, tn.x, smoothing * planen.x), pfma(keep, tn.y, smoothing * planen.y), pfma(keep, tn.z, smoothing * planen.z) });
     }
     else
       tbn2 = normalize3(planen);
 
-    float d0 = tbn2.x;
-    tbn0 = normalize3(f3{ 1 - d0 * tbn2.x, 0 - d0 * tbn2.y, 0 - d0 * tbn2.z });
+    #undef OCEAN_GEN_BLEND
+
+    // tbn[0] = normalize((1, 0, 0) - tbn[2].x * tbn[2])
+    p3 const tbn0 = normalize3(p3{ pfma(-tbn2.x, tbn2.x, 1.0f), -tbn2.x * tbn2.y, -tbn2.x * tbn2.z });
 
     OCEAN_STAMP(3);
 
-    // Mesh::Vertex { position3, texcoord2, normal3, tangent4 } = 48 bytes (src/renderer/mesh.h:20-26)
-    out[0] = make_float4(position.x - displacement.x, position.y - displacement.y, position.z + displacement.z, 0.1f * position.x);
-    out[1] = make_float4(0.1f * position.y, tbn2.x, tbn2.y, tbn2.z);
-    out[2] = make_float4(tbn0.x, tbn0.y, tbn0.z, -1.0f);
-  }
+    //-- Mesh::Vertex { position3, texcoord2, normal3, tangent4 } = 48 bytes (src/renderer/mesh.h:20-26) -----------
+    // The wave's 4 rows x 32 vertices = 4 x 96 float4 go through its 6 KB of LDS: lane i then stores float4 number
+    // i, 64 + i, ... 320 + i of the wave's 384 (three 16-byte stores per vertex at a 48-byte stride touch every line three times).
 
-  __device__ __forceinline__ void gen_vertex(GenArgs const &g, GlobalMap const &map, int xx, int yy, float4 (&out)[3])
-  {
-    GenRay ray;
-    GenTexels texels;
+    v2 const px = position.x - displacement.x, py = position.y - displacement.y, pz = position.z + displacement.z;
+    v2 const tu = 0.1f * position.x, tv = 0.1f * position.y;
 
-    gen_ray(g, xx, yy, ray);
-    gen_fetch(map, ray, texels);
-    gen_shade(g, ray, texels, out);
-  }
+    float4 *mine = reinterpret_cast<float4*>(smem) + 384 * wave;
 
-  // The wave's 4 rows x 16 vertices = 4 x 48 float4 go through its 3 KB of LDS: thread i then stores float4 number
-  // i, 64 + i, 128 + i of the wave's 192 (three 16-byte stores per thread at a 48-byte stride touched every line three
-  // times: 26 -> 21 us per 1024^2 mesh from 64^2 maps).
-  __device__ __forceinline__ void gen_store_tile(GenArgs const &g, float4 *stage, int tilex, int tiley, int tid, float4 const (&vtx)[3])
-  {
-    int const lane = tid & 63;
-    float4 *mine = stage + 3 * (tid - lane);       // this wave's 192 float4
+    #pragma unroll
+    for(int i = 0; i < 2; ++i)
+    {
+      float4 *vtx = mine + 3 * ((lane >> 4) * 32 + 16 * i + (lane & 15));
 
-    mine[3 * lane + 0] = vtx[0];
-    mine[3 * lane + 1] = vtx[1];
-    mine[3 * lane + 2] = vtx[2];
+      vtx[0] = make_float4(px[i], py[i], pz[i], tu[i]);
+      vtx[1] = make_float4(tv[i], tbn2.x[i], tbn2.y[i], tbn2.z[i]);
+      vtx[2] = make_float4(tbn0.x[i], tbn0.y[i], tbn0.z[i], -1.0f);
+    }
 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    int const x0 = tilex * GEN_TILE;
-    int const y0 = tiley * GEN_TILE + 4 * (tid >> 6);
-    int const rowlen = min(GEN_TILE, g.sizex - x0) * 3;                                // float4 of this tile in one mesh row
+    int const rowlen = min(GEN_TILE_X, g.sizex - x0) * 3;                                // float4 of this tile in one mesh row
+
+    // (the wave's part of the address is uniform: a scalar base and a 32-bit offset per lane)
+    float4 *out = reinterpret_cast<float4*>(g.vertices) + ((size_t)y0 * g.sizex + x0) * 3;
 
     #pragma unroll
-    for(int k = 0; k < 3; ++k)
+    for(int k = 0; k < 6; ++k)
     {
       int const j = 64 * k + lane;
-      int const r = j / 48, c = j % 48;
+      int const r = j / 96, c = j % 96;
 
 #ifdef OCEAN_GEN_ABLATE_STORES     // timing-only builds: the values stay live, nothing is written
       if (mine[j].w == 123456.789f)
 #endif
       if (c < rowlen && y0 + r < g.sizey)
-        reinterpret_cast<float4*>(g.vertices)[((size_t)(y0 + r) * g.sizex + x0) * 3 + c] = mine[j];
+        out[(unsigned)(r * g.sizex * 3 + c)] = mine[j];
     }
 
-  }
-
-#ifndef OCEAN_GEN_PIPELINED
-#define OCEAN_GEN_PIPELINED 0
-#endif
-#ifndef OCEAN_GEN_GROUPS_PER_CU
-#define OCEAN_GEN_GROUPS_PER_CU 5
-#endif
-
-  // One tile per workgroup, tiles in row-major order (68 VGPRs = 7 workgroups per CU; forced to 64 for 8: 18.7 against 17.7 us).
-  //
-  // OCEAN_GEN_PIPELINED (measured, off): persistent workgroups walk the tiles (workgroup b takes tiles b, b + gridDim.x, ...)
-  // and put the ray and swell arithmetic of the NEXT tile's vertex between the fetches of the current one and their use
-  // (the request after the last tile repeats it: no branch around loads, see GlobalMap).  96 VGPRs, five workgroups per
-  // CU: 35.7-37.3 us against 34.3 us from 1024^2 maps, 20.1-20.8 against 18.1 us from 64^2 maps, with 3 / 4 / 5 / 6 / 8
-  // workgroups per CU alike; every second workgroup starting 3.4 us late in the one-tile kernel: + 2.5-4.5 us
-  // (profiles/r02_gen_experiments.txt).
-  __global__ void __launch_bounds__(GEN_THREADS) ocean_gen_kernel(GenArgs g)
-  {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    float4 *stage = reinterpret_cast<float4*>(smem);
-
-    int const tid = threadIdx.x;
-
-    GlobalMap const map = { make_rsrc(g.map, (size_t)2 * g.N * g.N * sizeof(float4)) };
-
-#if OCEAN_GEN_PIPELINED
-    int const stride = (int)gridDim.x;
-    int tile = (int)blockIdx.x;
-
-    GenRay ray;
-    GenTexels texels;
-
-    gen_ray(g, (tile % g.tilesx) * GEN_TILE + (tid & 15), (tile / g.tilesx) * GEN_TILE + (tid >> 4), ray);
-    gen_fetch(map, ray, texels);
-
-    for(; tile < g.tiles; tile += stride)
-    {
-      int const next = (tile + stride < g.tiles) ? tile + stride : tile;
-
-      GenRay ahead;
-      gen_ray(g, (next % g.tilesx) * GEN_TILE + (tid & 15), (next / g.tilesx) * GEN_TILE + (tid >> 4), ahead);
-
-      // hipcc otherwise sinks this arithmetic below the shading (nothing there depends on it) and the fetches are waited
-      // for as soon as they are issued: pin `ahead` here and keep the scheduler from moving anything across
-      asm volatile("" :: "v"(ahead.position.x), "v"(ahead.position.y), "v"(ahead.position.z), "v"(ahead.w00), "v"(ahead.w10), "v"(ahead.w01), "v"(ahead.w11),
-                         "v"(ahead.t00), "v"(ahead.t10), "v"(ahead.t01), "v"(ahead.t11), "v"(ahead.smoothing), "v"(ahead.st), "v"(ahead.ct));
-      __builtin_amdgcn_sched_barrier(0);
-
-      float4 vtx[3];
-      gen_shade(g, ray, texels, vtx);
-      gen_store_tile(g, stage, tile % g.tilesx, tile / g.tilesx, tid, vtx);
-
-      ray = ahead;
-      gen_fetch(map, ray, texels);
-    }
-#else
-    int const tile = (int)blockIdx.x;
-    int const tilex = tile % g.tilesx, tiley = tile / g.tilesx;
-
-    float4 vtx[3];
-    gen_vertex(g, map, tilex * GEN_TILE + (tid & 15), tiley * GEN_TILE + (tid >> 4), vtx);
-    gen_store_tile(g, stage, tilex, tiley, tid, vtx);
-#endif
-
-#ifdef OCEAN_STAMPS
-    unsigned long long *stampbase = g.stamps + (size_t)blockIdx.x * 16;
-#endif
     OCEAN_STAMP_WHERE();
     OCEAN_STAMP(4);
+  }
+
+  inline GenLayout gen_layout(int N)
+  {
+    return (map_group_rows(N) == 2) ? GEN_PATCHED : (band_cols(N) != N) ? GEN_BANDED : GEN_PLAIN;
+  }
+
+  // everything but the set header, the map and the vertex buffer
+  inline void gen_shape(GenArgs &g, int N, int sizex, int sizey)
+  {
+    g.frame = make_gen_frame(g.set, N, sizex, sizey);
+    g.N = N;
+    g.sizex = sizex;
+    g.sizey = sizey;
+    g.tilesx = (sizex + GEN_TILE_X - 1) / GEN_TILE_X;
+    g.tiles = g.tilesx * ((sizey + GEN_TILE_Y - 1) / GEN_TILE_Y);
+    g.chunk = ((size_t)2 * N * N * sizeof(float4) > ((size_t)4 << 20)) ? OCEAN_GEN_XCD_CHUNK * g.tilesx : 0;
+  }
+
+  inline hipError_t launch_gen(GenArgs &g, hipStream_t stream)
+  {
+    void *args[] = { &g };
+    void const *kernel = nullptr;
+
+    switch(gen_layout(g.N))
+    {
+      case GEN_PLAIN: kernel = reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_PLAIN>); break;
+      case GEN_BANDED: kernel = reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_BANDED>); break;
+      case GEN_PATCHED: kernel = reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_PATCHED>); break;
+    }
+
+    int const groups = g.chunk ? ((g.tiles + 8 * g.chunk - 1) / (8 * g.chunk)) * 8 * g.chunk : g.tiles;
+
+    return hipLaunchKernel(kernel, dim3(groups), dim3(GEN_THREADS), args, GEN_LDS, stream);
   }
 }

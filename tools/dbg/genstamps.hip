@@ -19,7 +19,7 @@ int main() {
   constexpr int N = STAMP_N; int const sx = 1024, sy = 1024; size_t P = (size_t)N * N;
   float4 *maps; float *verts; unsigned long long *stamps;
   CK(hipMalloc(&maps, 2 * P * 16)); CK(hipMalloc(&verts, (size_t)sx * sy * 48));
-  int const tiles = (sx / 16) * (sy / 16);
+  int const tiles = ((sx + GEN_TILE_X - 1) / GEN_TILE_X) * ((sy + GEN_TILE_Y - 1) / GEN_TILE_Y);
   CK(hipMalloc(&stamps, (size_t)tiles * 16 * 8)); CK(hipMemset(stamps, 0, (size_t)tiles * 16 * 8));
   { std::vector<float4> h(2 * P); for (int y = 0; y < N; ++y) for (int x = 0; x < N; ++x) { h[map_index(N, y, x, 0)] = make_float4(0.1f * sinf(0.3f * x), 0.1f * cosf(0.2f * y), 0.2f * sinf(0.1f * (x + y)), 0); h[map_index(N, y, x, 1)] = make_float4(0.05f, 0.02f, 0.998f, 0); }
     CK(hipMemcpy(maps, h.data(), h.size() * 16, hipMemcpyHostToDevice)); }
@@ -40,8 +40,9 @@ int main() {
   memcpy(set.camera_dual, dual, 16);
   set.plane[2] = 1; set.swelllength = 40; set.swellamplitude = 0.8f; set.swelldirection[0] = 0.780869f; set.swelldirection[1] = 0.624695f;
   set.scale = 1 / 22.0f; set.choppiness = 1.35f; set.smoothing = 1 / 320.0f; set.size = N;
-  GenArgs g; g.set = set; g.frame = make_gen_frame(set); g.map = maps; g.N = N; g.sizex = sx; g.sizey = sy; g.tilesx = sx / 16; g.tiles = tiles; g.vertices = verts; g.stamps = stamps;
-  for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(ocean_gen_kernel, dim3(tiles), dim3(GEN_THREADS), GEN_LDS, 0, g);
+  GenArgs g; g.set = set; g.map = maps; g.vertices = verts; g.stamps = stamps; gen_shape(g, N, sx, sy);
+  if (g.tiles != tiles) { printf("tile count\n"); return 1; }
+  for (int it = 0; it < 5; ++it) CK(launch_gen(g, 0));
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> st((size_t)tiles * 16); CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
   char const *labels[4] = { "ray, plane hit, swell (arithmetic)", "fetches issued -> arrived", "shading", "staging + stores issued" };
@@ -64,5 +65,10 @@ int main() {
   std::map<unsigned, std::vector<int>> bycu;
   for (int b = 0; b < tiles; ++b) { unsigned hw = (unsigned)st[b * 16 + 15], xcc = (unsigned)st[b * 16 + 14] & 15; bycu[(xcc << 16) | (hw & 0xff00 & ~0u)].push_back(b); }
   printf("   distinct (XCC, SE, CU) seen: %zu\n", bycu.size());
+  printf("   where workgroups ran (b: xcc/se.sh.cu start-us):");
+  for (int b = 0; b < 48; ++b) { unsigned hw = (unsigned)st[b * 16 + 15], xcc = (unsigned)st[b * 16 + 14] & 15; if (b % 8 == 0) printf("\n    "); printf(" %d:%u/%u.%u.%u@%.2f", b, xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (st[b * 16] - t0) * 0.01); }
+  printf("\n   workgroups sharing the CU of workgroup 0:");
+  { unsigned key0 = (((unsigned)st[14] & 15) << 16) | ((unsigned)st[15] & 0xff00); for (int b : bycu[key0]) printf(" %d@%.2f", b, (st[(size_t)b * 16] - t0) * 0.01); }
+  printf("\n");
   return 0;
 }
