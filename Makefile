@@ -13,7 +13,14 @@ HOSTDEPS = datum_amd/host/ocean.h datum_amd/host/lml.h include/datum_ocean_hip.h
 CXX ?= g++
 HOSTFLAGS ?= -O2 -std=c++14 -fPIC -ffp-contract=off -fno-fast-math -Wall
 
-all: $(LIB) $(HOSTLIB) oracle examples
+# measurement aid of bench.py --standin-peers (a CU-occupying stand-in for the all-gather on one GPU); not the ocean path
+STANDIN = datum_amd/lib/libdatum_farm_standin.so
+
+all: $(LIB) $(HOSTLIB) $(STANDIN) oracle examples
+
+$(STANDIN): datum_amd/csrc/farm_standin.hip
+	@mkdir -p datum_amd/lib
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -o $@ datum_amd/csrc/farm_standin.hip
 
 # the C++ host shim links only against the C ABI of the HIP module
 $(HOSTLIB): $(HOSTSRC) $(HOSTDEPS) $(LIB)
@@ -51,7 +58,7 @@ resource-usage: $(SRC) $(DEPS)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(SRC) 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" 
 
 clean:
-	rm -f $(LIB) $(HOSTLIB) $(EMUL) $(EXAMPLE) $(EXTMEM)
+	rm -f $(LIB) $(HOSTLIB) $(STANDIN) $(EMUL) $(EXAMPLE) $(EXTMEM)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle emul helpers examples clean resource-usage

@@ -4,6 +4,8 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (no launcher: bench.py starts its own N ranks, see launch_ranks)
+  python bench.py --gpus 8 --resolution 2048 --cascades 1      BASELINE.json configs[3]: 2048^2 x 8 tiles, one per GPU
 
 A "step" = one update_ocean(dt = 1/60) + one displacement pass (phase advance, ocean.sim, row IFFT, column IFFT,
 ocean.map: SURVEY.md 8d) over this rank's batch of independent cascades.  Default workload = BASELINE.json
@@ -42,6 +44,10 @@ def parse():
                     help="N > 1: the one all-gather per batch of --steps steps that reassembles the displacement field. pipelined: the collective "
                          "of the previous batch runs on a second stream under this batch's kernels (double-buffered payload); serial: after the "
                          "batch's last step, on the compute stream; none: left out")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="N > 1: 0 = ONE all-gather per timed batch of --steps steps (north_star's single all-gather); K >= 1: the displacement "
+                         "field is packed and gathered every K steps (1 = every step), each gather overlapped with the following steps when "
+                         "--gather pipelined")
     ap.add_argument("--payload", choices=("xyz32", "xyz16", "maps"), default="xyz32",
                     help="what a rank contributes to the all-gather: the displacement field as floats (12 B/pt, exact), as halves (8 B/pt), or both "
                          "map layers (32 B/pt)")
@@ -51,6 +57,14 @@ def parse():
     ap.add_argument("--standin-peers", type=int, default=0,
                     help="1 GPU only (overhead measurement): run the pack kernel and, on the second stream, the HBM writes of this many peers' payloads "
                          "in place of the collective")
+    ap.add_argument("--standin-workgroups", type=int, default=32,
+                    help="--standin-peers: workgroups of the stand-in kernel on the second stream (RCCL's channels are workgroups that copy); "
+                         "0 = device-to-device copies, which occupy no compute unit")
+    ap.add_argument("--standin-gbps", type=float, default=300.0,
+                    help="--standin-peers: bus bandwidth the stand-in is paced to (0 = as fast as HBM takes it)")
+    ap.add_argument("--plumbing", action="store_true",
+                    help="no GPU: every rank joins a gloo group on the CPU, all-reduces its rank and rank 0 prints one JSON line -- the launcher, "
+                         "the environment and the rendezvous of an N-rank run without the ocean (tests/test_bench_launcher.py)")
     ap.add_argument("--spectrum", choices=("fp32", "fp16"), default="fp32",
                     help="storage of the work spectrum between the two passes (fp16: BASELINE.json configs[4]; arithmetic stays fp32)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
@@ -98,20 +112,24 @@ def lavapipe_probe(N):
     icd = sorted(glob.glob("/usr/share/vulkan/icd.d/lvp_icd*.json") + glob.glob("/etc/vulkan/icd.d/lvp_icd*.json"))
     glsl = shutil.which("glslangValidator")
     header = os.path.exists("/usr/include/vulkan/vulkan.h")
-    missing = [n for n, v in (("libvulkan", loader), ("vulkan headers", header), ("lvp ICD", icd), ("glslangValidator", glsl)) if not v]
+    cc = shutil.which("cc") or shutil.which("gcc")
+    found = {"libvulkan": loader or None, "vulkan headers": "/usr/include/vulkan/vulkan.h" if header else None, "lvp ICD": icd[0] if icd else None,
+             "glslangValidator": glsl, "cc": cc}
+    missing = [n for n, v in found.items() if not v]
     if missing:
-        return "unavailable: no " + ", no ".join(missing)
+        return {"status": "unavailable: no " + ", no ".join(missing), "probe": found}
     if N > 1024:
-        return "available, but the harness runs N <= 1024"
+        return {"status": "available, but the harness runs N <= 1024", "probe": found}
     d = os.path.join(ROOT, "tools", "lavapipe")
     try:
         subprocess.run(["make", "-C", d, f"N={N}"], check=True, capture_output=True, timeout=120)
         subprocess.run([sys.executable, os.path.join(d, "make_state.py"), str(N)], check=True, capture_output=True, timeout=120)
         out = subprocess.run([os.path.join(d, "harness"), str(N), "50"], cwd=d, env=dict(os.environ, VK_ICD_FILENAMES=icd[0]),
                              capture_output=True, text=True, timeout=300)
-        return "this repository's N-generalised restatement of the reference shaders (tools/lavapipe): " + out.stdout.strip().replace("\n", " | ")
+        return {"status": "this repository's N-generalised restatement of the reference shaders (tools/lavapipe): " + out.stdout.strip().replace("\n", " | "),
+                "probe": found}
     except Exception as e:  # noqa: BLE001
-        return f"toolchain present but the harness failed: {e}"
+        return {"status": f"toolchain present but the harness failed: {e}", "probe": found}
 
 
 def cpu_baseline(N, cascades, states, budget):
@@ -140,12 +158,116 @@ def cpu_baseline(N, cascades, states, budget):
                        f"oracle/ocean_oracle.cpp with OpenMP over rows/columns")
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start N ranks of this same command as CHILD
+    processes -- before torch is imported or the GPU touched in this process, and never by exec -- one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would.  Rank 0's stdout (the
+    JSON line) is relayed; everything else goes to stderr.  Exit code: 0 only if every rank exited 0."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DATUM_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+
+    # rank 0's output is collected by a thread while every rank is watched: when one rank dies the others would sit in the
+    # rendezvous or a collective for ever, so they are given a few seconds and then ended (by their PIDs)
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 10.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.1)
+
+    reader.join(timeout=5.0)
+    out = "".join(c for c in chunks if c)
+    codes = [p.returncode for p in procs]
+
+    # stdout carries the JSON line(s) only; what libraries print there (RCCL's and gloo's banners) goes to stderr
+    for l in (out or "").splitlines():
+        if l.strip():
+            print(l, file=sys.stdout if l.lstrip().startswith("{") else sys.stderr, flush=True)
+
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
+def plumbing(rank, world):
+    """--plumbing: the N-rank rendezvous on the CPU over gloo (no GPU, no ocean)."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t)
+    g = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(g, torch.tensor([float(rank)], dtype=torch.float64))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"plumbing": "ok", "backend": "gloo", "world_size": dist.get_world_size(), "sum_of_ranks": float(t.item()),
+                          "ranks_seen": [int(v.item()) for v in g], "launcher": "bench.py" if os.environ.get("DATUM_BENCH_CHILD") else "external"}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+def baseline_config(N, C, world, spectrum):
+    """Which BASELINE.json config a run is (or is the per-GPU share of)."""
+    if spectrum == "fp16" and N == 4096:
+        return "BASELINE.json configs[4]" + ("" if world == 1 else f", one such grid set per GPU x {world}")
+    if (N, C) == (2048, 1) and world > 1:
+        return f"BASELINE.json configs[3]: 2048x2048 tiles, one per GPU, {world} of its 8" if world != 8 else "BASELINE.json configs[3]: 2048x2048 x 8 tiles farmed across 8 GPUs"
+    if (N, C) == (2048, 1):
+        return "the per-GPU share of BASELINE.json configs[3] (one 2048x2048 tile)"
+    if (N, C) == (1024, 4):
+        return "BASELINE.json configs[2]" + ("" if world == 1 else f" per GPU, farmed x {world} (weak scaling of configs[2]; configs[3]'s own shape is --resolution 2048 --cascades 1)")
+    if (N, C) == (512, 1):
+        return "BASELINE.json configs[1]" + ("" if world == 1 else f" per GPU x {world}")
+    return "no BASELINE.json config has this shape"
+
+
 def main():
     args = parse()
+
+    # N ranks without a launcher: this process only starts them (nothing below runs here)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    if args.gpus != world:      # before anything touches the GPU
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (own launcher) or under "
+              f"torch.distributed.run with --nproc-per-node equal to --gpus", file=sys.stderr, flush=True)
+        return 2
+
+    if os.environ.get("DATUM_BENCH_FAIL_RANK") == str(rank):      # tests/test_bench_launcher.py: a rank that dies at start
+        return 3
+
+    if args.plumbing:
+        return plumbing(rank, world)
 
     import torch
     import torch.distributed as dist
@@ -159,8 +281,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
-
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from datum_amd import capi, farm, host_api
 
@@ -197,7 +317,7 @@ def main():
         pbytes = oc.payload_bytes(code)
         assert pbytes == farm.payload_bytes(N, C, args.payload)
         tg = farm.TileGather(farm.payload_numel(N, C, args.payload), pdtype, dev, world, standin_peers=args.standin_peers,
-                             force_collective=args.force_collective)
+                             force_collective=args.force_collective, standin_workgroups=args.standin_workgroups, standin_gbps=args.standin_gbps)
 
     def step():
         oc.update(DT)
@@ -215,7 +335,7 @@ def main():
         pack()
         tg.launch()
         tg.result()
-        if args.gather == "pipelined":
+        if args.gather == "pipelined" and args.gather_every == 0:
             pack()
 
     torch.cuda.synchronize(dev)
@@ -225,7 +345,7 @@ def main():
 
     # kernel durations for the roofline: HIP events around the two kernels of every 8th step of the timed loop, on
     # the stream they run on (bracketing every step would cost ~10 % of the throughput being measured)
-    stride = 8 if args.steps >= 16 else 1
+    stride = 8 if args.steps >= 64 else (2 if args.steps >= 16 else 1)
     oc.profile_begin((args.steps + stride - 1) // stride, stride)
     ev0, ev1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
 
@@ -233,10 +353,28 @@ def main():
     # batch's (its payload was packed above), issued first and running on the communication stream while this batch's kernels
     # run; this batch's payload is packed at the end and would be gathered under the next batch.  serial: this batch's own
     # payload is packed and gathered after its last step.
+    # --gather-every K: a pack and a gather after every K steps instead (K = 1: the field is reassembled every step).
+    every = args.gather_every if gathering else 0
+    gathers = 0
+    slot = None
     t0 = time.perf_counter()
     ev0.record(stream)
-    if gathering and args.gather == "pipelined":
+    if every > 0:
+        for i in range(args.steps):
+            step()
+            if (i + 1) % every == 0:
+                pack()
+                slot = tg.launch()
+                gathers += 1
+                if args.gather == "serial":
+                    tg.result()
+        if slot is None:
+            pack()
+            slot = tg.launch()
+            gathers += 1
+    elif gathering and args.gather == "pipelined":
         slot = tg.launch()
+        gathers = 1
         for _ in range(args.steps):
             step()
         pack()
@@ -245,6 +383,7 @@ def main():
             step()
         pack()
         slot = tg.launch()
+        gathers = 1
         tg.result()
     else:
         for _ in range(args.steps):
@@ -353,14 +492,23 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{N}x{N} x {C} cascades per GPU, {'fp32 arithmetic, fp16-stored spectrum' if args.spectrum == 'fp16' else 'fp32'}"
-                            + (", phase advance + sim + row IFFT + column IFFT + map (BASELINE.json configs[2])" if (N, C) == (1024, 4) else ""),
+                            f", phase advance + sim + row IFFT + column IFFT + map: {baseline_config(N, C, world, args.spectrum)}",
+                "baseline_config": baseline_config(N, C, world, args.spectrum),
                 "resolution": N,
                 "cascades_per_gpu": C,
                 "grids_per_step": C * world,
-                "gather": (f"{args.gather}: one all-gather of the {args.payload} payload per {args.steps} steps, inside the timed region"
-                           + (" (the previous batch's, on a second stream under this batch's kernels)" if args.gather == "pipelined" else ""))
+                "gather": ((f"{args.gather}: one all-gather of the {args.payload} payload every {every} step(s), {gathers} inside the timed region"
+                            + (", each on a second stream under the following steps' kernels" if args.gather == "pipelined" else "")) if every > 0 else
+                           (f"{args.gather}: one all-gather of the {args.payload} payload per {args.steps} steps, inside the timed region"
+                            + (" (the previous batch's, on a second stream under this batch's kernels)" if args.gather == "pipelined" else "")))
                           if (multi and args.gather != "none") else ("none" if multi else
-                          (f"n/a (1 GPU; stand-in for {args.standin_peers} peers' payload writes on a second stream)" if args.standin_peers else "n/a (1 GPU)")),
+                          (f"n/a (1 GPU; stand-in for {args.standin_peers} peers' payloads on a second stream: "
+                           + (f"{args.standin_workgroups} workgroups paced to {args.standin_gbps:g} GB/s" if args.standin_workgroups else "device-to-device copies")
+                           + (f", every {every} step(s)" if every > 0 else f", once per {args.steps} steps") + ")" if args.standin_peers else "n/a (1 GPU)")),
+                "gathers_in_timed_region": gathers,
+                "collective_world_size": (dist.get_world_size() if multi else None),
+                "collective_backend": ("nccl (RCCL)" if multi else None),
+                "measured_on_hardware": ("this line" if world > 1 else "1 GPU"),
                 "payload": args.payload if gathering else None,
                 "payload_bytes_per_rank": pbytes if gathering else None,
                 "parallelism": f"tile-farm x{world}",
@@ -407,6 +555,8 @@ def main():
     if multi:
         dist.destroy_process_group()
 
+    return 0
+
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,0 +1,85 @@
+// farm_standin.hip -- MEASUREMENT AID for bench.py --standin-peers on ONE GPU; not part of the ocean path and not in
+// include/datum_ocean_hip.h.  What an RCCL all-gather does to the chip that runs the displacement step while it is in
+// flight, without a second GPU: a kernel of a few dozen workgroups (RCCL's channels are workgroups that copy) that stays
+// resident for as long as the collective would, reads this rank's payload once per peer and writes the peers' payloads into
+// the gathered buffer (the HBM writes of the tiles arriving over xGMI), paced to a stated bus bandwidth with the
+// device-wide clock.  A device-to-device hipMemcpy (round 2's stand-in) occupies no compute unit and runs at HBM speed.
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace
+{
+  constexpr int THREADS = 256;
+  constexpr size_t CHUNK = (size_t)THREADS * 16 * 8;       // bytes a workgroup moves between two looks at the clock
+
+  // s_memrealtime: 100 MHz, one clock for the whole device
+  __device__ __forceinline__ unsigned long long realtime()
+  {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+  }
+
+  // dst[peer][...] = src[...] for `peers` peers; workgroup g takes chunks g, g + gridDim.x, ...; after each chunk it waits
+  // until the clock has reached what `ticks_per_chunk` allows for the chunks it has moved
+  __global__ void __launch_bounds__(THREADS) standin_kernel(uint4 *dst, uint4 const *src, size_t bytes, int peers, float ticks_per_chunk)
+  {
+    size_t const chunks = (bytes + CHUNK - 1) / CHUNK;
+    size_t const total = chunks * peers;
+    unsigned long long const t0 = realtime();
+    size_t done = 0;
+
+    for(size_t item = blockIdx.x; item < total; item += gridDim.x)
+    {
+      size_t const peer = item / chunks, chunk = item % chunks;
+      size_t const first = chunk * (CHUNK / 16), last = min((chunk + 1) * (CHUNK / 16), bytes / 16);
+
+      if (last - first == CHUNK / 16)
+      {
+        uint4 v[8];                            // eight loads in flight per lane, then eight stores
+
+        #pragma unroll
+        for(int k = 0; k < 8; ++k)
+          v[k] = src[first + threadIdx.x + k * THREADS];
+
+        #pragma unroll
+        for(int k = 0; k < 8; ++k)
+          dst[peer * (bytes / 16) + first + threadIdx.x + k * THREADS] = v[k];
+      }
+      else
+      {
+        for(size_t i = first + threadIdx.x; i < last; i += THREADS)
+          dst[peer * (bytes / 16) + i] = src[i];
+      }
+
+      done += 1;
+
+      if (ticks_per_chunk > 0)
+      {
+        unsigned long long const until = t0 + (unsigned long long)(ticks_per_chunk * (float)done);
+
+        while (realtime() < until)
+          __builtin_amdgcn_s_sleep(8);
+      }
+    }
+  }
+}
+
+// bytes: a multiple of 16.  gbps: the bus bandwidth the copy is paced to (bytes * peers / duration), 0 = as fast as it goes.
+extern "C" int datum_farm_standin_gather(void *gathered, void const *payload, size_t bytes, int peers, int workgroups, double gbps, void *stream)
+{
+  if (!gathered || !payload || (bytes & 15) || peers < 1 || workgroups < 1)
+    return -1;
+
+  size_t const chunks = (bytes + CHUNK - 1) / CHUNK;
+
+  // a workgroup moves total / workgroups chunks in the time the whole transfer may take
+  double const seconds = gbps > 0 ? (double)bytes * peers / (gbps * 1e9) : 0.0;
+  double const mine = (double)(chunks * peers) / workgroups;
+  float const ticks = gbps > 0 ? (float)(seconds * 1e8 / mine) : 0.0f;
+
+  hipLaunchKernelGGL(standin_kernel, dim3(workgroups), dim3(THREADS), 0, (hipStream_t)stream, (uint4*)gathered, (uint4 const*)payload, bytes, peers, ticks);
+
+  return (int)hipGetLastError();
+}

@@ -95,19 +95,34 @@ class TileGather:
                                             # pack by an event; returns at once, the next batch's kernels overlap it
         ...
         out = tg.result()                   # (any later time) the consuming stream waits for the oldest launched slot
+        ... the consumer reads out on ITS stream ...
+        tg.release()                        # the consumer's stream is done with it: the slot's next collective waits for this
 
     On CUDA/HIP the ordering is by events between the producer's stream and an own communication stream; on CPU (gloo)
     the collective is issued with async_op=True and result() waits on its handle.  world == 1: no collective, result()
     returns the payload itself.
     """
 
-    def __init__(self, numel, dtype, device, world, slots=2, standin_peers=0, force_collective=False):
-        # standin_peers (measurement aid, one GPU only): in place of the collective, the communication stream writes
-        # the payload `standin_peers` times into the gathered buffer -- the HBM writes of that many peers' tiles arriving
-        # -- so that the cost of the pack kernel plus a concurrently busy second stream can be measured without a node
+    def __init__(self, numel, dtype, device, world, slots=2, standin_peers=0, force_collective=False, standin_workgroups=32, standin_gbps=0.0):
+        # standin_peers (measurement aid, one GPU only): in place of the collective, the communication stream runs a kernel of
+        # `standin_workgroups` workgroups (RCCL's channels are workgroups that copy) that writes the payload `standin_peers`
+        # times into the gathered buffer -- the HBM writes of that many peers' tiles arriving -- paced to `standin_gbps` of
+        # bus bandwidth (0: as fast as it goes; standin_workgroups == 0: device-to-device copies, which occupy no CU):
+        # datum_amd/csrc/farm_standin.hip.  What a busy second stream costs the step, without a node.
         # force_collective (tests): issue the collective in a one-rank process group too
         assert standin_peers == 0 or world == 1
         self.standin = standin_peers
+        self.standin_workgroups = standin_workgroups
+        self.standin_gbps = standin_gbps
+        self.standin_lib = None
+        if standin_peers and standin_workgroups:
+            import ctypes
+            import os
+
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdatum_farm_standin.so")
+            self.standin_lib = ctypes.CDLL(path)      # fails loudly when the library was not built
+            self.standin_lib.datum_farm_standin_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                                                   ctypes.c_double, ctypes.c_void_p]
         self.world = world
         self.collective = world > 1 or force_collective
         self.device = torch.device(device)
@@ -117,6 +132,8 @@ class TileGather:
         self.gathered = [torch.empty(parts * numel, dtype=dtype, device=self.device) if parts else None for _ in range(slots)]
         self.work = [None] * slots           # gloo: async handles
         self.done = [None] * slots           # cuda: event recorded behind the slot's collective
+        self.consumed = [None] * slots       # cuda: event recorded by release() on the consumer's stream
+        self.handed = None                   # slot last handed out by result()
         self.head = 0                        # next slot to acquire
         self.acquired = None
         self.pending = []                    # launched, not yet handed out by result()
@@ -148,10 +165,19 @@ class TileGather:
                 self.packed[s].record(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.comm):
                     self.comm.wait_event(self.packed[s])
+                    if self.consumed[s] is not None:
+                        self.comm.wait_event(self.consumed[s])     # WAR: a consumer on another stream may still read gathered[s]
+                        self.consumed[s] = None
                     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     start.record(self.comm)
                     if self.collective:
                         dist.all_gather_into_tensor(self.gathered[s], self.payload[s])
+                    elif self.standin_lib is not None:
+                        n = self.payload[s].numel()
+                        rc = self.standin_lib.datum_farm_standin_gather(self.gathered[s][n:].data_ptr(), self.payload[s].data_ptr(),
+                                                                        n * self.payload[s].element_size(), self.standin, self.standin_workgroups,
+                                                                        self.standin_gbps, self.comm.cuda_stream)
+                        assert rc == 0, f"datum_farm_standin_gather: {rc}"
                     else:
                         n = self.payload[s].numel()
                         for k in range(1, 1 + self.standin):
@@ -168,6 +194,7 @@ class TileGather:
         """Gathered buffer of the OLDEST launched batch (ordered by global grid index); the current stream waits for it."""
         assert self.pending, "nothing launched"
         s = self.pending.pop(0)
+        self.handed = s
         if not self.collective and not self.standin:
             return self.payload[s]
         if self.cuda:
@@ -176,6 +203,17 @@ class TileGather:
             self.work[s].wait()
             self.work[s] = None
         return self.gathered[s]
+
+    def release(self, slot=None):
+        """The consumer (current stream) has finished reading the buffer result() handed out: the slot's next collective
+        is ordered behind this point.  Needed when the consumer's stream is not the producing stream (on the producing
+        stream the order is already there: acquire / pack / launch of the slot come later on that stream)."""
+        s = self.handed if slot is None else slot
+        if s is None or not self.cuda:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.consumed[s] = ev
 
     def last_collective_ms(self, slot):
         """Duration of the slot's last collective on the communication stream (CUDA/HIP only, after it has finished)."""
