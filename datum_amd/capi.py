@@ -20,7 +20,8 @@ D = ctypes.c_double
 SUPPORTED = (64, 128, 256, 512, 1024, 2048, 4096)
 MAX_CASCADES = 16
 
-OK, EINVAL, ESTATE, ENOMEM = 0, -1, -2, -3
+OK, EINVAL, ESTATE, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
+ENOTREADY = 1
 PAYLOAD_MAPS, PAYLOAD_XYZ32, PAYLOAD_XYZ16 = 0, 1, 2
 
 
@@ -59,6 +60,9 @@ SYMBOLS = {
     "datum_ocean_set_spectrum_format": (I, [P, I]),
     "datum_ocean_upload_state": (I, [P, I, P, P]),
     "datum_ocean_read_state": (I, [P, I, P]),
+    "datum_ocean_state_bytes": (ctypes.c_size_t, [I]),
+    "datum_ocean_park_state": (I, [P, I, P, ctypes.c_size_t, ctypes.POINTER(I)]),
+    "datum_ocean_resume_state": (I, [P, I, P, ctypes.c_size_t, I]),
     "datum_ocean_upload_seed": (I, [P, I, P]),
     "datum_ocean_rebuild_height": (I, [P, I, F, F, F, F, F]),
     "datum_ocean_read_height": (I, [P, I, P]),
@@ -71,6 +75,8 @@ SYMBOLS = {
     "datum_ocean_sync": (I, [P]),
     "datum_ocean_wait_event": (I, [P, P]),
     "datum_ocean_signal": (I, [P, ctypes.POINTER(P)]),
+    "datum_ocean_on_complete": (I, [P, ctypes.CFUNCTYPE(None, ctypes.c_void_p), P]),
+    "datum_ocean_query": (I, [P]),
     "datum_ocean_import_memory_fd": (I, [P, I, ctypes.c_size_t, ctypes.POINTER(P)]),
     "datum_ocean_release_memory": (I, [P, P]),
     "datum_ocean_import_semaphore_fd": (I, [P, I, ctypes.POINTER(P)]),
@@ -236,6 +242,29 @@ class Ocean:
 
     def release_memory(self, device_ptr):
         self._check(self.lib.datum_ocean_release_memory(self.h, P(device_ptr)))
+
+    def signal(self):
+        """Record the handle's completion event behind everything enqueued so far; returns the hipEvent_t."""
+        p = P()
+        self._check(self.lib.datum_ocean_signal(self.h, ctypes.byref(p)))
+        return p.value
+
+    def wait_event(self, hip_event):
+        self._check(self.lib.datum_ocean_wait_event(self.h, P(hip_event)))
+
+    def query(self):
+        """True once everything enqueued before the last signal() has finished; never blocks."""
+        rc = self.lib.datum_ocean_query(self.h)
+        if rc == ENOTREADY:
+            return False
+        self._check(rc)
+        return True
+
+    def on_complete(self, fn):
+        """`fn()` on a runtime thread once everything enqueued so far has finished.  The ctypes trampoline is kept alive on the handle."""
+        cb = ctypes.CFUNCTYPE(None, ctypes.c_void_p)(lambda _user: fn())
+        self._callbacks = getattr(self, "_callbacks", []) + [cb]
+        self._check(self.lib.datum_ocean_on_complete(self.h, cb, None))
 
     def import_semaphore_fd(self, fd):
         p = P()

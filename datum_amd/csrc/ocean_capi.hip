@@ -744,6 +744,71 @@ int datum_ocean_read_state(datum_ocean_t ctx, int cascade, float *phase)
   return DATUM_OCEAN_OK;
 }
 
+size_t datum_ocean_state_bytes(int resolution)
+{
+  return (size_t)resolution * resolution * (sizeof(float2) + sizeof(float));
+}
+
+int datum_ocean_park_state(datum_ocean_t ctx, int cascade, void *device_dst, size_t bytes, int *flags)
+{
+  if (!ctx || !device_dst || !flags)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_park_state: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_park_state: cascade out of range");
+
+  if (bytes != datum_ocean_state_bytes(ctx->N))
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_park_state: buffer must be datum_ocean_state_bytes()");
+
+  if (!ctx->uploaded[cascade])
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_park_state: the cascade holds no state");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  int rc = flush_pending(ctx, 0);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  size_t const P = plane(ctx);
+
+  HIPCHECK(ctx, hipMemcpyAsync(device_dst, ctx->h0 + cascade * P, P * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHECK(ctx, hipMemcpyAsync(static_cast<char*>(device_dst) + P * sizeof(float2), ctx->phase + cascade * P, P * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+
+  *flags = ctx->wildphase[cascade] ? 1 : 0;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_resume_state(datum_ocean_t ctx, int cascade, void const *device_src, size_t bytes, int flags)
+{
+  if (!ctx || !device_src)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_resume_state: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_resume_state: cascade out of range");
+
+  if (bytes != datum_ocean_state_bytes(ctx->N))
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_resume_state: buffer must be datum_ocean_state_bytes()");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  // updates queued against the state that is being replaced are applied first (the other cascades keep them)
+  int rc = flush_pending(ctx, 0);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  size_t const P = plane(ctx);
+
+  HIPCHECK(ctx, hipMemcpyAsync(ctx->h0 + cascade * P, device_src, P * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHECK(ctx, hipMemcpyAsync(ctx->phase + cascade * P, static_cast<char const*>(device_src) + P * sizeof(float2), P * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+
+  ctx->wildphase[cascade] = (flags & 1) != 0;
+  ctx->uploaded[cascade] = true;
+  ctx->scaledirty[cascade] = true;
+
+  return DATUM_OCEAN_OK;
+}
+
 int datum_ocean_update(datum_ocean_t ctx, float dt)
 {
   if (!ctx)
@@ -962,6 +1027,40 @@ int datum_ocean_signal(datum_ocean_t ctx, void **hip_event)
   return DATUM_OCEAN_OK;
 }
 
+int datum_ocean_on_complete(datum_ocean_t ctx, void (*callback)(void *user), void *user)
+{
+  if (!ctx || !callback)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_on_complete: null argument");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipLaunchHostFunc(ctx->stream, callback, user));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_query(datum_ocean_t ctx)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_query: null handle");
+
+  if (!ctx->complete)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_query: datum_ocean_signal first");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  hipError_t const e = hipEventQuery(ctx->complete);
+
+  if (e == hipErrorNotReady)
+  {
+    (void)hipGetLastError();
+    return DATUM_OCEAN_ENOTREADY;
+  }
+
+  HIPCHECK(ctx, e);
+
+  return DATUM_OCEAN_OK;
+}
+
 int datum_ocean_import_memory_fd(datum_ocean_t ctx, int fd, size_t bytes, void **device_ptr)
 {
   if (!ctx || !device_ptr)
@@ -1016,7 +1115,10 @@ int datum_ocean_release_memory(datum_ocean_t ctx, void *device_ptr)
       HIPCHECK(ctx, hipSetDevice(ctx->device));
       HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));    // nothing enqueued may still write it
 
-      if (ctx->maps == device_ptr)
+      // (a VkBuffer commonly sits at an offset inside its VkDeviceMemory: the maps may be bound anywhere inside the block)
+      char const *lo = static_cast<char const*>(device_ptr), *hi = lo + ctx->importedmemory[i].bytes;
+
+      if (reinterpret_cast<char const*>(ctx->maps) >= lo && reinterpret_cast<char const*>(ctx->maps) < hi)
         ctx->maps = ctx->ownmaps;
 
       hipError_t e = hipDestroyExternalMemory(ctx->importedmemory[i].memory);
@@ -1051,7 +1153,16 @@ int datum_ocean_import_semaphore_fd(datum_ocean_t ctx, int fd, void **semaphore)
 
   hipExternalSemaphore_t sem = nullptr;
 
-  HIPCHECK(ctx, hipImportExternalSemaphore(&sem, &desc));
+  hipError_t const e = hipImportExternalSemaphore(&sem, &desc);
+
+  if (e == hipErrorNotSupported)
+  {
+    (void)hipGetLastError();
+    return fail(ctx, DATUM_OCEAN_EUNSUPPORTED, "datum_ocean_import_semaphore_fd: this HIP runtime has no external semaphores (hipImportExternalSemaphore: not supported); "
+                                               "bridge rendercomplete on the host: datum_ocean_on_complete or datum_ocean_signal + datum_ocean_query");
+  }
+
+  HIPCHECK(ctx, e);
 
   ctx->importedsemaphores.push_back(sem);
 

@@ -102,6 +102,7 @@ extern "C"
   }
 
   void datum_host_params_set_deviceheight(void *p, int on) { static_cast<OceanParams*>(p)->deviceheight = (on != 0); }
+  void datum_host_params_set_hostphase(void *p, int on) { static_cast<OceanParams*>(p)->hostphase = (on != 0); }
 
   float *datum_host_params_seed(void *p) { return static_cast<OceanParams*>(p)->seed.data(); }
   float *datum_host_params_height(void *p) { return static_cast<OceanParams*>(p)->height.data(); }

@@ -30,6 +30,15 @@ namespace
       throw runtime_error(string(what) + ": " + datum_ocean_last_error(hip));
   }
 
+  // omega(k) = sqrt(g |k| (1 + k^2 / 370^2))   (ocean.cpp:82-87)
+  float dispersion(Vec2 const &k)
+  {
+    float const wm = 370.0f;
+    float const knorm = sqrt(normsqr(k));
+
+    return sqrt(9.81f * knorm * (1.0f + normsqr(k) / (wm * wm)));
+  }
+
   // Phillips spectrum P(k) for wind speed v along w, amplitude a (ocean.cpp:89-107):
   // a * d * exp(-1/(k^2 L^2)) / k^6 * (k.w)^2 * exp(-k^2 l^2), L = v^2/g, l = L/1000,
   // waves running against the wind damped by d = 0.2; no energy at k = 0.
@@ -132,7 +141,67 @@ namespace
     params.updates.clear();
     params.firstupdate = 0;
     params.phaseupdates = 0;
+    params.baselineage = 0;
     params.stateid = g_stateids++;
+  }
+
+  // update_ocean's phase loop (ocean.cpp:223-233) on the host, for one recorded step (OceanParams::hostphase only)
+  void advance_host_phase(OceanParams &params, OceanParams::Update const &u)
+  {
+    int const N = params.resolution;
+
+    for(int m = 0; m < N; ++m)
+    {
+      float const y = 2*pi<float>() * (m - 0.5f*N) / u.wavescale;
+
+      for(int n = 0; n < N; ++n)
+      {
+        float const x = 2*pi<float>() * (n - 0.5f*N) / u.wavescale;
+
+        float &ph = params.phase[(size_t)m*N + n];
+
+        ph = fmod(ph + dispersion(Vec2(x, y)) * u.dt, 2*pi<float>());
+      }
+    }
+  }
+
+  // park the state that is resident on the context's device (h0 + phase, device to device) under its ids
+  void park_bound_state(OceanContext &context)
+  {
+    if (context.boundstate == 0)
+      return;
+
+    size_t const bytes = datum_ocean_state_bytes(context.resolution);
+
+    OceanContext::Parked *slot = nullptr;
+
+    for(auto &p : context.parked)
+      if (p.stateid == context.boundstate)
+        slot = &p;
+
+    if (!slot && context.parked.size() < OceanContext::MaxParkedStates)
+    {
+      context.parked.emplace_back();
+      slot = &context.parked.back();
+      check(context.hip, datum_ocean_device_alloc(context.hip, bytes, &slot->device), "datum_ocean_device_alloc");
+    }
+
+    if (!slot)
+    {
+      slot = &context.parked[0];
+
+      for(auto &p : context.parked)      // least recently used
+        if (p.lastuse < slot->lastuse)
+          slot = &p;
+    }
+
+    check(context.hip, datum_ocean_park_state(context.hip, 0, slot->device, bytes, &slot->flags), "datum_ocean_park_state");
+
+    slot->stateid = context.boundstate;
+    slot->heightid = context.boundheight;
+    slot->appliedupdates = context.appliedupdates;
+    slot->appliedlineage = context.appliedlineage;
+    slot->lastuse = ++context.useclock;
   }
 
   // make the device hold this params' state: h0 (and phase when the whole state was replaced), then every update_ocean
@@ -141,24 +210,53 @@ namespace
   {
     assert(params.resolution == context.resolution);
 
-    if (context.boundstate != params.stateid)
-    {
-      // params.phase is the state as of seed_ocean / the last fetch_ocean_state: the recorded history from there on comes on top
-      if (params.phaseupdates < params.firstupdate)
-        throw runtime_error("ocean: the update history behind OceanParams::phase is no longer recorded (fetch_ocean_state at least every OceanParams::MaxRecordedUpdates update_ocean calls before moving a state to another context)");
-
-      check(context.hip, datum_ocean_set_cascade(context.hip, 0, params.wavescale, params.choppiness), "datum_ocean_set_cascade");
-      check(context.hip, datum_ocean_upload_state(context.hip, 0, params.height.data(), params.phase.data()), "datum_ocean_upload_state");
-
-      context.boundstate = params.stateid;
-      context.boundheight = params.heightid;
-      context.appliedupdates = params.phaseupdates;
-    }
-
     uint64_t const last = params.firstupdate + params.updates.size();
 
-    if (context.appliedupdates < params.firstupdate)
-      throw runtime_error("ocean: more than OceanParams::MaxRecordedUpdates update_ocean calls since this context last rendered the state");
+    // what the device holds can be continued with this params' history if it is the same state, not further along than the
+    // history goes, not behind what the history still records, and came out of this very history (lineage)
+    auto continues = [&](uint64_t stateid, uint64_t applied, uint64_t lineage) {
+      return stateid == params.stateid && applied >= params.firstupdate && applied <= last && params.lineage_at(applied) == lineage;
+    };
+
+    if (!continues(context.boundstate, context.appliedupdates, context.appliedlineage))
+    {
+      if (context.boundstate != params.stateid)
+        park_bound_state(context);
+
+      OceanContext::Parked *slot = nullptr;
+
+      for(auto &p : context.parked)
+        if (continues(p.stateid, p.appliedupdates, p.appliedlineage))
+          slot = &p;
+
+      if (slot)
+      {
+        // rendered here before: the parked phase is ahead of (or level with) params.phase
+        check(context.hip, datum_ocean_resume_state(context.hip, 0, slot->device, datum_ocean_state_bytes(context.resolution), slot->flags), "datum_ocean_resume_state");
+
+        context.boundstate = params.stateid;
+        context.boundheight = slot->heightid;
+        context.appliedupdates = slot->appliedupdates;
+        context.appliedlineage = slot->appliedlineage;
+
+        slot->lastuse = ++context.useclock;
+      }
+      else
+      {
+        // params.phase is the state as of seed_ocean / the last fetch_ocean_state (or as far as update_ocean had to carry it
+        // when the history was trimmed): the recorded history from there on comes on top
+        if (params.phaseupdates < params.firstupdate)
+          throw runtime_error("ocean: this context holds no copy of the state and the update history behind OceanParams::phase is no longer recorded: render or fetch_ocean_state a state at least every OceanParams::MaxRecordedUpdates / 2 update_ocean calls, or set OceanParams::hostphase");
+
+        check(context.hip, datum_ocean_set_cascade(context.hip, 0, params.wavescale, params.choppiness), "datum_ocean_set_cascade");
+        check(context.hip, datum_ocean_upload_state(context.hip, 0, params.height.data(), params.phase.data()), "datum_ocean_upload_state");
+
+        context.boundstate = params.stateid;
+        context.boundheight = params.heightid;
+        context.appliedupdates = params.phaseupdates;
+        context.appliedlineage = params.lineage_at(params.phaseupdates);
+      }
+    }
 
     // the steps issued before a lerp_ocean_waves advanced the phase with the dispersion of the OLD wave scale
     // (ocean.cpp:225-231 uses params.wavescale as it is at the call): replay each step under its own
@@ -170,7 +268,8 @@ namespace
       check(context.hip, datum_ocean_update(context.hip, u.dt), "datum_ocean_update");
     }
 
-    context.appliedupdates = max(context.appliedupdates, last);
+    context.appliedupdates = last;
+    context.appliedlineage = params.lineage_at(last);
 
     // (a change of wave scale applies the updates queued on the device under the old one first: datum_ocean_set_cascade)
     check(context.hip, datum_ocean_set_cascade(context.hip, 0, params.wavescale, params.choppiness), "datum_ocean_set_cascade");
@@ -274,7 +373,12 @@ OceanParams::OceanParams(int resolution)
 OceanContext::~OceanContext()
 {
   if (hip)
+  {
+    for(auto &p : parked)
+      datum_ocean_device_free(hip, p.device);
+
     datum_ocean_destroy(hip);
+  }
 }
 
 
@@ -337,12 +441,32 @@ void update_ocean(OceanParams &params, float dt)
 
   // phase[m][n] = fmod(phase[m][n] + dispersion(k)*dt, 2 pi) is done by the row-pass kernel, in history order, with the
   // dispersion of the wave scale in force now
-  params.updates.push_back(OceanParams::Update{ dt, params.wavescale });
+  uint32_t dtbits, wsbits;
+  memcpy(&dtbits, &dt, 4);
+  memcpy(&wsbits, &params.wavescale, 4);
+
+  uint64_t const prev = params.updates.empty() ? params.baselineage : params.updates.back().lineage;
+  uint64_t const lineage = ((prev ^ dtbits) * 0x100000001b3ull ^ wsbits) * 0x100000001b3ull + 0x9e3779b97f4a7c15ull;
+
+  params.updates.push_back(OceanParams::Update{ dt, params.wavescale, lineage });
+
+  // extension: keep the host copy of the phase current as the reference does (ocean.cpp:223-233), for a params that must be
+  // renderable by a context that has never seen it at any time, however long ago it was last rendered or fetched
+  if (params.hostphase)
+  {
+    while (params.phaseupdates < params.firstupdate + params.updates.size())
+    {
+      advance_host_phase(params, params.updates[params.phaseupdates - params.firstupdate]);
+
+      params.phaseupdates += 1;
+    }
+  }
 
   if (params.updates.size() > OceanParams::MaxRecordedUpdates)
   {
     size_t const drop = params.updates.size() - OceanParams::MaxRecordedUpdates / 2;
 
+    params.baselineage = params.updates[drop - 1].lineage;
     params.updates.erase(params.updates.begin(), params.updates.begin() + drop);
     params.firstupdate += drop;
   }
@@ -564,6 +688,7 @@ void fetch_ocean_state(OceanContext &context, OceanParams &params)
   check(context.hip, datum_ocean_read_state(context.hip, 0, params.phase.data()), "datum_ocean_read_state");
 
   // the host phase now contains the whole history: none of it needs to be kept for a later upload of these params
+  params.baselineage = params.lineage_at(params.firstupdate + params.updates.size());
   params.phaseupdates = params.firstupdate + params.updates.size();
   params.firstupdate = params.phaseupdates;
   params.updates.clear();

@@ -144,6 +144,23 @@ struct OceanContext
   std::uint64_t boundheight = 0;
   std::uint64_t boundseed = 0;            // which OceanParams seed is resident on the device (deviceheight only)
   std::uint64_t appliedupdates = 0;       // how many of that state's update_ocean calls the device has applied (OceanParams::updates)
+  std::uint64_t appliedlineage = 0;       // OceanParams::lineage_at(appliedupdates) of the history those updates came from
+
+  // States this context has rendered before and had to make room for: h0 and the phase as advanced so far, parked in
+  // device memory (datum_ocean_park_state), so that alternating between several OceanParams on one context costs two
+  // device-to-device copies per switch and replays only the updates issued since -- the reference keeps every params'
+  // phase on the host and any context renders any params at any time (ocean.cpp:217-236,748-749).
+  struct Parked
+  {
+    std::uint64_t stateid = 0, heightid = 0, appliedupdates = 0, appliedlineage = 0, lastuse = 0;
+    void *device = nullptr;
+    int flags = 0;
+  };
+
+  static const std::size_t MaxParkedStates = 4;
+
+  std::vector<Parked> parked;
+  std::uint64_t useclock = 0;
 
   OceanContext() = default;
   OceanContext(OceanContext const &) = delete;
@@ -183,6 +200,11 @@ struct OceanParams
   // then stale until fetch_ocean_state().  Off by default (the reference recomputes on the host).
   bool deviceheight = false;
 
+  // extension: also advance `phase` on the host in every update_ocean call, as the reference does (ocean.cpp:223-233; N * N
+  // fmod per call).  Off by default: the phase lives on the device (and in the contexts' parked copies); the host copy is
+  // the state as of seed_ocean / the last fetch_ocean_state and is only needed by a context that holds no copy.
+  bool hostphase = false;
+
   // device residency bookkeeping (not in the reference)
   //
   // update_ocean's phase loop runs on the device, so update_ocean() only RECORDS the step: entry number
@@ -190,9 +212,14 @@ struct OceanParams
   // belongs to the state (stateid), not to one OceanParams object: OceanParams stays freely copyable like the reference's
   // POD -- a per-frame copy handed to the render thread carries the same stateid and a prefix-consistent history -- and
   // rendering is const: render_ocean_surface applies the entries the CONTEXT has not applied yet
-  // (OceanContext::appliedupdates) and never touches the params.  The history keeps the last MaxRecordedUpdates entries;
-  // a context that falls further behind than that throws.
-  struct Update { float dt, wavescale; };
+  // (OceanContext::appliedupdates) and never touches the params.  The history keeps the last MaxRecordedUpdates entries.  A
+  // context that alternates between several params parks the one it is not rendering (OceanContext::Parked) and continues
+  // from there; only a context that holds NO copy of a state whose host phase is older than the recorded history throws
+  // (render or fetch a state every MaxRecordedUpdates / 2 steps, or set hostphase).
+  // (lineage: a running hash over the history up to and including this entry.  A copy of an OceanParams that is then
+  // advanced on its own -- update_ocean(P, a), update_ocean(Q, b) -- shares P's stateid and history NUMBERS but not their
+  // contents; a context tells the two apart by the lineage of the last entry it applied.)
+  struct Update { float dt, wavescale; std::uint64_t lineage; };
 
   static const std::size_t MaxRecordedUpdates = 4096;
 
@@ -201,6 +228,10 @@ struct OceanParams
   std::uint64_t firstupdate = 0;        // history number of updates[0]
   std::vector<Update> updates;          // update_ocean calls since firstupdate
   std::uint64_t phaseupdates = 0;       // how many entries of the history `phase` (on the host) already contains
+  std::uint64_t baselineage = 0;        // lineage of history entry firstupdate - 1 (0 at the start of a history)
+
+  // lineage of the history's first `count` entries (count in [firstupdate, firstupdate + updates.size()])
+  std::uint64_t lineage_at(std::uint64_t count) const { return count == firstupdate ? baselineage : updates[count - firstupdate - 1].lineage; }
   int rejectedseeds = 0;                // seed pairs whose 8 polar draws were all rejected (see seed_ocean)
 
   explicit OceanParams(int resolution = OceanContext::WaveResolution);

@@ -65,6 +65,7 @@ def load():
             "datum_host_params_get": (None, [P, ctypes.POINTER(Scalars)]),
             "datum_host_params_set": (None, [P, ctypes.POINTER(Scalars)]),
             "datum_host_params_set_deviceheight": (None, [P, I]),
+            "datum_host_params_set_hostphase": (None, [P, I]),
             "datum_host_params_seed": (ctypes.POINTER(F), [P]),
             "datum_host_params_height": (ctypes.POINTER(F), [P]),
             "datum_host_params_phase": (ctypes.POINTER(F), [P]),
@@ -151,6 +152,10 @@ class OceanParams:
     def set_deviceheight(self, on=True):
         """Extension: lerp_ocean_waves leaves the h0 rebuild to the device (datum_ocean_rebuild_height)."""
         self.lib.datum_host_params_set_deviceheight(self.p, 1 if on else 0)
+
+    def set_hostphase(self, on=True):
+        """Extension: update_ocean also advances the host copy of the phase, as the reference does (ocean.cpp:223-233)."""
+        self.lib.datum_host_params_set_hostphase(self.p, 1 if on else 0)
 
     def seed_ocean(self, rngseed=None):
         self.lib.datum_host_seed_ocean(self.p, 0 if rngseed is None else rngseed, 1 if rngseed is None else 0)

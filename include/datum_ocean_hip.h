@@ -36,7 +36,9 @@ enum
   DATUM_OCEAN_OK = 0,
   DATUM_OCEAN_EINVAL = -1,    /* bad argument (null pointer, unsupported resolution, cascade out of range) */
   DATUM_OCEAN_ESTATE = -2,    /* call order misuse (e.g. displace before upload_state)                     */
-  DATUM_OCEAN_ENOMEM = -3
+  DATUM_OCEAN_ENOMEM = -3,
+  DATUM_OCEAN_EUNSUPPORTED = -4   /* the HIP runtime on this machine lacks the feature (external semaphores on ROCm 7.0.x: use the
+                                   host bridge, datum_ocean_on_complete / datum_ocean_query)                                  */
 };
 
 typedef struct datum_ocean_ctx *datum_ocean_t;
@@ -108,6 +110,16 @@ int datum_ocean_set_spectrum_format(datum_ocean_t ctx, int format);
 int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, float const *phase);
 int datum_ocean_read_state(datum_ocean_t ctx, int cascade, float *phase);
 
+/* Park a cascade's state (h0 and the phase as advanced so far: 12 * N * N bytes, h0 first) in caller-owned DEVICE memory,
+ * and bring a parked state back -- device to device on the handle's stream, no host round trip.  For a host object that
+ * renders more states than the handle has cascades (the reference keeps every OceanParams' phase on the host and uploads
+ * it per frame, ocean.cpp:748-749, so any context can render any params at any time; here the phase lives on the device).
+ * Updates queued by datum_ocean_update are applied before either call.  `flags` carries what the module knows about
+ * the parked phase (pass back what park returned).  bytes must be datum_ocean_state_bytes(). */
+size_t datum_ocean_state_bytes(int resolution);
+int datum_ocean_park_state(datum_ocean_t ctx, int cascade, void *device_dst, size_t bytes, int *flags);
+int datum_ocean_resume_state(datum_ocean_t ctx, int cascade, void const *device_src, size_t bytes, int flags);
+
 /* Device-side spectrum rebuild (what lerp_ocean_waves does on the host, ocean.cpp:194-211):
  * keep OceanParams::seed (N*N*2 floats, ocean.cpp:140-141) resident and recompute
  * h0 = seed * dk * sqrt(phillips(k, waveamplitude, windspeed, winddirection) / 2), dk = 2 pi / wavescale,
@@ -160,6 +172,19 @@ int datum_ocean_sync(datum_ocean_t ctx);
 int datum_ocean_wait_event(datum_ocean_t ctx, void *hip_event);
 int datum_ocean_signal(datum_ocean_t ctx, void **hip_event);
 
+/* The host bridge for `rendercomplete` (ocean.cpp:341,803; waited on at renderer.cpp:6848) where the runtime cannot
+ * import a VkSemaphore (hipImportExternalSemaphore returns "not supported" on ROCm 7.0.x: import_semaphore_fd then fails with
+ * DATUM_OCEAN_EUNSUPPORTED):
+ *   on_complete  `callback(user)` runs on a runtime thread once everything enqueued on the handle's stream so far has
+ *                finished -- the integrator signals the renderer from it (vkSignalSemaphore on a timeline semaphore, or an
+ *                empty vkQueueSubmit that signals the binary `rendercomplete`).  No HIP call may be made from the callback.
+ *   query        DATUM_OCEAN_OK when everything enqueued before the last datum_ocean_signal has finished,
+ *                DATUM_OCEAN_ENOTREADY while it has not; never blocks (a renderer that polls once per frame).
+ * INTEGRATION.md 3a has the call sequence. */
+#define DATUM_OCEAN_ENOTREADY 1
+int datum_ocean_on_complete(datum_ocean_t ctx, void (*callback)(void *user), void *user);
+int datum_ocean_query(datum_ocean_t ctx);
+
 /* -- Vulkan <-> HIP interop, the HIP half --------------------------------------------------
  * In datum the Ocean mesh's vertex buffer is a VkBuffer the graphics queue draws from (ocean.cpp:270, bound at
  * geometrylist.cpp:463,513) and the frame's submit waits on the ocean's `rendercomplete` VkSemaphore (ocean.cpp:803,
@@ -171,7 +196,9 @@ int datum_ocean_signal(datum_ocean_t ctx, void **hip_event);
  *                        descriptor belongs to the handle (do not close it); released by release_memory or destroy.
  *   import_semaphore_fd  hipImportExternalSemaphore; signal_external / wait_external enqueue a signal / a wait on the
  *                        handle's stream: the rendercomplete semaphore and the up to 8 wait dependencies of the
- *                        reference's submit (vulkan.cpp:1308-1328).
+ *                        reference's submit (vulkan.cpp:1308-1328).  Returns DATUM_OCEAN_EUNSUPPORTED where the runtime
+ *                        has no external semaphores (ROCm 7.0.x on the MI355X boxes: only the MEMORY import has ever
+ *                        succeeded there, profiles/r02_external_memory_probe.txt); the host bridge above is what works.
  * INTEGRATION.md has the Vulkan side of the handshake. */
 int datum_ocean_import_memory_fd(datum_ocean_t ctx, int fd, size_t bytes, void **device_ptr);
 int datum_ocean_release_memory(datum_ocean_t ctx, void *device_ptr);

@@ -197,3 +197,116 @@ def test_render_from_per_frame_copies(oracle):
         ctx.displace_ocean_surface(blank)
         m = ctx.read_displacement()
         assert np.all(m[0] == 0) and np.abs(m[1][..., 2] - 1).max() < 1e-6
+
+
+def test_two_oceans_on_one_context_for_longer_than_the_history(oracle):
+    # Two OceanParams rendered alternately through ONE OceanContext, as two oceans (or several cascades driven through the
+    # host API) would be, for more update_ocean calls than the history records (OceanParams::MaxRecordedUpdates = 4096).
+    # The reference keeps each params' phase on the host, so any context renders any params at any time
+    # (ocean.cpp:217-236); here the context parks the state it is not rendering on the device and continues from there:
+    # every step applied exactly once to the right state, no growth of the work per frame, no exception.
+    import time
+
+    import numpy as np
+
+    from datum_amd import host_api
+
+    N = 64
+    dt = np.float32(1 / 60)
+    ws = (22.0, 64.0)
+    ps = []
+    for k in range(2):
+        p = host_api.OceanParams(N, **dict(host_api.EXAMPLE_TUNABLES, wavescale=ws[k]))
+        p.seed_ocean(1000 + k)
+        ps.append(p)
+    phases = [np.zeros((N, N), np.float32) for _ in range(2)]
+    steps = 4400
+    laps = []
+    with host_api.OceanContext(N, device=0) as ctx:
+        for frame in range(steps):
+            t0 = time.perf_counter()
+            for k in range(2):
+                ps[k].update_ocean(dt)
+                ctx.displace_ocean_surface(ps[k])
+            if frame in (99, steps - 1):
+                ctx.read_displacement()            # drain the stream: the lap times are host times
+            laps.append(time.perf_counter() - t0)
+        for k in range(2):
+            for _ in range(steps):
+                oracle.update(phases[k], ws[k], dt)
+            ctx.fetch_ocean_state(ps[k])
+            assert np.array_equal(ps[k].phase, phases[k]), k
+        # the last frames cost what the first frames cost (round 2: a replay of the whole history on every switch)
+        early, late = np.median(laps[100:400]), np.median(laps[-300:])
+        assert late < 3 * early + 1e-4, (early, late)
+        # and the maps are the second ocean's after rendering the second ocean
+        want = oracle.displace(ps[1].height.copy(), phases[1].copy(), ws[1], 1.35, w=oracle.weights(N))
+        ctx.displace_ocean_surface(ps[1])
+        got = ctx.read_displacement()
+        assert np.sqrt(((got.astype(np.float64) - want) ** 2).mean()) < 1e-5
+
+
+def test_diverged_copies_share_an_id_but_not_a_history(oracle):
+    # copy P to Q, then advance them differently: the reference's PODs diverge freely.  Both carry the same state id and
+    # history numbers; the context must notice (lineage of the last applied entry) and render each with its own phase.
+    import numpy as np
+
+    from datum_amd import host_api
+
+    N = 64
+    e = oracle.EXAMPLE
+    a, b = np.float32(1 / 60), np.float32(1 / 24)
+    P = host_api.OceanParams(N, **host_api.EXAMPLE_TUNABLES)
+    P.seed_ocean(1000)
+    pp, pq = np.zeros((N, N), np.float32), np.zeros((N, N), np.float32)
+    with host_api.OceanContext(N, device=0) as ctx:
+        for _ in range(3):
+            P.update_ocean(a)
+            oracle.update(pp, e["wavescale"], a)
+            oracle.update(pq, e["wavescale"], a)
+            ctx.displace_ocean_surface(P)
+        Q = P.copy()
+        for _ in range(5):
+            P.update_ocean(a)
+            oracle.update(pp, e["wavescale"], a)
+            Q.update_ocean(b)
+            oracle.update(pq, e["wavescale"], b)
+            ctx.displace_ocean_surface(P)
+            ctx.displace_ocean_surface(Q)
+        ctx.fetch_ocean_state(Q)
+        ctx.fetch_ocean_state(P)
+        assert np.array_equal(P.phase, pp)
+        assert np.array_equal(Q.phase, pq)
+        assert not np.array_equal(pp, pq)
+
+
+def test_a_context_that_never_saw_the_state(oracle):
+    # 4500 update_ocean calls without a render or a fetch: the history no longer reaches back to params.phase.  With
+    # OceanParams::hostphase the host copy is advanced as the reference does it and any context can start from it;
+    # without, the first render by a context that holds no copy fails loudly instead of rendering a wrong phase.
+    import numpy as np
+
+    from datum_amd import host_api
+
+    N = 64
+    dt = np.float32(1 / 60)
+    e = oracle.EXAMPLE
+    steps = 4500
+    kept = host_api.OceanParams(N, **host_api.EXAMPLE_TUNABLES)
+    kept.seed_ocean(1000)
+    kept.set_hostphase(True)
+    lost = host_api.OceanParams(N, **host_api.EXAMPLE_TUNABLES)
+    lost.seed_ocean(1000)
+    phase = np.zeros((N, N), np.float32)
+    for _ in range(steps):
+        kept.update_ocean(dt)
+        lost.update_ocean(dt)
+        oracle.update(phase, e["wavescale"], dt)
+    assert np.array_equal(kept.phase, phase)          # the host loop is the reference's, bit for bit the oracle's
+    with host_api.OceanContext(N, device=0) as ctx:
+        ctx.displace_ocean_surface(kept)
+        ctx.fetch_ocean_state(kept)
+        assert np.array_equal(kept.phase, phase)
+        with pytest.raises(RuntimeError) as err:
+            ctx.displace_ocean_surface(lost)
+        assert "hostphase" in str(err.value)

@@ -131,3 +131,28 @@ def test_oceanset_header_matches_oracle(host, oracle):
 def test_twiddle_table_is_the_reference_formula(host, oracle):
     for N in (64, 512):
         assert np.array_equal(host.twiddle_table(N), oracle.weights(N))
+
+
+def test_hostphase_is_the_reference_loop(host, oracle):
+    # OceanParams::hostphase: update_ocean also advances the host copy of the phase with the reference's own loop
+    # (ocean.cpp:223-233), bit for bit the oracle's -- through a change of wave scale and past the point where the recorded
+    # history (OceanParams::MaxRecordedUpdates = 4096 entries) is trimmed.  Without it the host copy stays where it was.
+    N = 32
+    dt = np.float32(1 / 60)
+    e = oracle.EXAMPLE
+    p = host.OceanParams(N, **host.EXAMPLE_TUNABLES)
+    p.seed_ocean(1000)
+    p.set_hostphase(True)
+    q = p.copy()
+    q.set_hostphase(False)
+    phase = np.zeros((N, N), np.float32)
+    for i in range(4300):
+        if i == 100:
+            p.lerp_ocean_waves(64.0, e["waveamplitude"], e["windspeed"], e["winddirection"], 1.0)
+        ws = float(p.scalars().wavescale)
+        p.update_ocean(dt)
+        q.update_ocean(dt)
+        oracle.update(phase, ws, dt)
+    assert np.array_equal(p.phase, phase)
+    assert np.all(q.phase == 0)
+    assert p.scalars().pending <= 4096 and q.scalars().pending <= 4096
