@@ -88,12 +88,15 @@ def measured_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/):
     bench.py cannot run the profiler on itself, so the value is the latest committed measurement for exactly this
     kernel, workload AND kernel source (hash recorded by tools/profile_gpu.sh), or None when any of them differs."""
-    try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        if j.get("workload") == workload and kernel in j["kernels"] and j.get("kernel_source_sha256_16") == kernel_source_hash():
-            return j["kernels"][kernel]["traffic_bytes"], "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB; same kernel sources)"
-    except Exception:
-        pass
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+            if j.get("workload") == workload and kernel in j["kernels"] and j.get("kernel_source_sha256_16") == kernel_source_hash():
+                return j["kernels"][kernel]["traffic_bytes"], f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, KiB; same kernel sources)"
+        except Exception:  # noqa: BLE001
+            pass
     return None, None
 
 

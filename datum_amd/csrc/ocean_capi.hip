@@ -119,7 +119,7 @@ namespace
   hipError_t configure_one(char const **what)
   {
     *what = "hipFuncSetAttribute(ocean_rowpass_kernel, MaxDynamicSharedMemorySize)";
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N, H16>::LDS);
     if (e != hipSuccess)
       return e;
 
@@ -158,19 +158,25 @@ namespace
     return hipLaunchKernel(kernel, grid, block, args, lds, stream);
   }
 
-  template<int N>
-  hipError_t launch_rowpass(datum_ocean_ctx *ctx, StepArgs &a, hipEvent_t *ev)
+  template<int N, bool H16>
+  hipError_t launch_rowpass_as(datum_ocean_ctx *ctx, StepArgs &a, hipEvent_t *ev)
   {
+    typedef RowCfg<N, H16> C;
+
     void *args[] = { &a };
-    void const *kernel = ctx->half ? reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, true>) : reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>);
+    void const *kernel = reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>);
 
     // work items = groups of row pairs x cascades: one workgroup each, or (largest grids) one persistent workgroup per
     // compute unit that walks its share
-    int const items = RowCfg<N>::GROUPS * ctx->cascades;
+    int const items = C::GROUPS * ctx->cascades;
 
-    int const percu = RowCfg<N>::PER_CU;
+    return launch(kernel, dim3(C::WALK ? std::min(items, ctx->cus * C::PER_CU) : items), dim3(C::THREADS), args, C::LDS, ctx->stream, ev);
+  }
 
-    return launch(kernel, dim3(row_walks<N>() ? std::min(items, ctx->cus * percu) : items), dim3(RowCfg<N>::THREADS), args, RowCfg<N>::LDS, ctx->stream, ev);
+  template<int N>
+  hipError_t launch_rowpass(datum_ocean_ctx *ctx, StepArgs &a, hipEvent_t *ev)
+  {
+    return ctx->half ? launch_rowpass_as<N, true>(ctx, a, ev) : launch_rowpass_as<N, false>(ctx, a, ev);
   }
 
   template<int N>

@@ -546,25 +546,39 @@ namespace ocean
 #define OCEAN_ROW_EARLY 3          // walking row pass: the parts of the next pair's inputs requested BEFORE the transforms (see request): h0 and its mirror row
 #endif
 
-  template<int N>
+#ifndef OCEAN_ROW_E16_FROM
+#define OCEAN_ROW_E16_FROM 4096      // row pass: 16 points per thread from this resolution up (half the threads per row pair)
+#endif
+#ifndef OCEAN_ROW_SEQ_FROM
+#define OCEAN_ROW_SEQ_FROM 4096      // row pass: the two packed fields one after the other through ONE LDS line per row (half the LDS)
+#endif
+#ifndef OCEAN_ROW_SEQ_FP32
+#define OCEAN_ROW_SEQ_FP32 0         // ... with the fp32-stored spectrum too
+#endif
+
+  template<int N, bool H16 = false>
   struct RowCfg
   {
-    static constexpr int E = default_radix(N);
+    static constexpr int E = (N >= OCEAN_ROW_E16_FROM) ? 16 : default_radix(N);
     static constexpr int T = Plan<N, E>::T;
 #ifndef OCEAN_ROW_PAIR_THREADS
 #define OCEAN_ROW_PAIR_THREADS 128   // threads of a row-pass workgroup when one row pair needs fewer (small grids are
 #endif                               // latency-bound: more, smaller workgroups; 512^2 x 1: 9.2 us against 9.9 us with 256)
     static constexpr int PAIRS = (2 * T >= OCEAN_ROW_PAIR_THREADS) ? 1 : OCEAN_ROW_PAIR_THREADS / (2 * T);   // row pairs per workgroup
     static constexpr int THREADS = 2 * T * PAIRS;
-    static constexpr int K = 2;
+    // one field per set of barrier phases, the other waits in registers -- with the fp16-stored spectrum only: as halves C's
+    // results wait in 16 registers, as floats in 32 and the kernel spills (4096^2 fp32: 155 against 132 us)
+    static constexpr bool SEQ = (N >= OCEAN_ROW_SEQ_FROM) && (H16 || OCEAN_ROW_SEQ_FP32);
+    static constexpr int K = SEQ ? 1 : 2;                                  // LDS lines per row
     static constexpr int PS = 4;
     static constexpr int LINE = LineFFT<N, PS, E>::LINE + 2;               // + element 0 again at index N (the Hermitian swap), kept 16-byte aligned
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
-    static constexpr bool WALK = (N >= OCEAN_ROW_WALK_FROM) && PAIRS == 1;       // see ocean_rowpass_kernel
+    static constexpr bool WALK = (N >= OCEAN_ROW_WALK_FROM) && PAIRS == 1 && !SEQ;       // see ocean_rowpass_kernel
     static constexpr size_t LDS = ((size_t)LineFFT<N, 4, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)4 * T : 0)) * sizeof(cf);      // + the walking variant's twiddle stash
 
     static constexpr int PER_CU = (LDS * 2 <= (size_t)160 * 1024) ? 2 : 1;                     // persistent workgroups per compute unit (walking)
-    static constexpr int MIN_WAVES = WALK ? (THREADS / 64) * PER_CU / 4 : 1;                    // per SIMD, for __launch_bounds__
+    static constexpr int FIT = (int)(((size_t)160 * 1024) / LDS);                              // workgroups per CU the LDS allows
+    static constexpr int MIN_WAVES = WALK ? (THREADS / 64) * PER_CU / 4 : (SEQ ? ((THREADS / 64) * (FIT > 4 ? 4 : FIT) + 3) / 4 : 1);   // per SIMD, for __launch_bounds__
 
     static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
   };
@@ -623,12 +637,12 @@ namespace ocean
   // is unconditional (the last pair requests itself again: under "if (more)" the old inputs stay live as the other arm of
   // the merge), the thread's twiddles wait in LDS between pairs, and its coordinates are re-derived per pair from an opaque
   // copy of its index.  (Two rows per thread in 512-thread workgroups: 96 registers of inputs on top of 209 in 256.)
-  template<int N> constexpr bool row_walks() { return RowCfg<N>::WALK; }
+  template<int N, bool H16 = false> constexpr bool row_walks() { return RowCfg<N, H16>::WALK; }
 
   template<int N, bool H16>
-  __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) ocean_rowpass_kernel(StepArgs a)
+  __global__ void __launch_bounds__((RowCfg<N, H16>::THREADS), (RowCfg<N, H16>::MIN_WAVES)) ocean_rowpass_kernel(StepArgs a)
   {
-    typedef RowCfg<N> C;
+    typedef RowCfg<N, H16> C;
     typedef Plan<N, C::E> P;
     typedef LineFFT<N, 4, C::E> L;
 
@@ -737,7 +751,7 @@ namespace ocean
     OCEAN_STAMP_WHERE();
     OCEAN_STAMP(0);
 
-    constexpr bool WALK = row_walks<N>();
+    constexpr bool WALK = row_walks<N, H16>();
 
     static_assert(!WALK || 1 + LineTw<N, E>::type::NMIDREG + P::M <= 4, "twiddle stash");
 
@@ -794,9 +808,10 @@ namespace ocean
       int const y = row_of(item);
       int const otherhalf = (p == 0) ? half : 1 - half;
 
+      // (SEQ: the row's one line is the swap buffer first and the transforms' line afterwards)
       cf *line = midtab + L::MIDTAB + (pr * 2 + half) * K * C::LINE;
-      cf *swap_out = line + C::LINE;
-      cf const *swap_in = midtab + L::MIDTAB + (pr * 2 + otherhalf) * K * C::LINE + C::LINE;
+      cf *swap_out = line + (K - 1) * C::LINE;
+      cf const *swap_in = midtab + L::MIDTAB + (pr * 2 + otherhalf) * K * C::LINE + (K - 1) * C::LINE;
 
       CascadeConst const cc = a.casc[cascade];
 
@@ -861,7 +876,7 @@ namespace ocean
       float const cy = (y == 0) ? -2.0f : 0.0f;
       float const cx = (t == 0) ? -2.0f : 0.0f;
 
-      cf v[K][E];
+      cf v[2][E];
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
@@ -903,7 +918,14 @@ namespace ocean
       };
 
 #ifndef OCEAN_ABLATE_ROWFFT
-      fft_lines<N, K, C::PS, E>(v, t, line, C::LINE, midtab, w, true, rest);
+      if constexpr (C::SEQ)
+      {
+        // C through the row's line, then D through the same line; C's results wait in registers for the one store per point
+        fft_lines<N, 1, C::PS, E>(reinterpret_cast<cf (&)[1][E]>(v[0]), t, line, C::LINE, midtab, w, true);
+        fft_lines<N, 1, C::PS, E>(reinterpret_cast<cf (&)[1][E]>(v[1]), t, line, C::LINE, midtab, w, true, rest);
+      }
+      else
+        fft_lines<N, K, C::PS, E>(v, t, line, C::LINE, midtab, w, true, rest);
 #else
       rest();
 #endif

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 d, workload = sys.argv[1], sys.argv[2]
-out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r02_traffic.json")
+out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03_traffic.json")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON the GPU box: the round's profile set (kernel trace + PMC passes per size), traffic file, test log, bench lines
-R=${R:-r02}
+R=${R:-r03}
 tools/profile_gpu.sh ${R}_prof_1024x4 > /dev/null 2>&1
 python tools/make_traffic_json.py gpurun_out/${R}_prof_1024x4 "1024x1024 x 4 cascades" gpurun_out/${R}_traffic.json > /dev/null
 tools/profile_gpu.sh ${R}_prof_512x1 --resolution 512 --cascades 1 --steps 2000 --warmup 200 > /dev/null 2>&1
