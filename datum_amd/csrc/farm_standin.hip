@@ -23,7 +23,8 @@ namespace
 
   // dst[peer][...] = src[...] for `peers` peers; workgroup g takes chunks g, g + gridDim.x, ...; after each chunk it waits
   // until the clock has reached what `ticks_per_chunk` allows for the chunks it has moved
-  __global__ void __launch_bounds__(THREADS) standin_kernel(uint4 *dst, uint4 const *src, size_t bytes, int peers, float ticks_per_chunk)
+  // mode 0: copy; 1: resident only (no memory traffic); 2: reads only; 3: writes only (what arrives over xGMI costs no reads here)
+  __global__ void __launch_bounds__(THREADS) standin_kernel(uint4 *dst, uint4 const *src, size_t bytes, int peers, float ticks_per_chunk, int mode)
   {
     size_t const chunks = (bytes + CHUNK - 1) / CHUNK;
     size_t const total = chunks * peers;
@@ -35,17 +36,34 @@ namespace
       size_t const peer = item / chunks, chunk = item % chunks;
       size_t const first = chunk * (CHUNK / 16), last = min((chunk + 1) * (CHUNK / 16), bytes / 16);
 
-      if (last - first == CHUNK / 16)
+      if (last - first == CHUNK / 16 && mode != 1)
       {
         uint4 v[8];                            // eight loads in flight per lane, then eight stores
 
         #pragma unroll
         for(int k = 0; k < 8; ++k)
-          v[k] = src[first + threadIdx.x + k * THREADS];
+          v[k] = (mode == 3) ? make_uint4(k, peer, chunk, 0) : src[first + threadIdx.x + k * THREADS];
 
-        #pragma unroll
-        for(int k = 0; k < 8; ++k)
-          dst[peer * (bytes / 16) + first + threadIdx.x + k * THREADS] = v[k];
+        if (mode == 2)
+        {
+          unsigned acc = 0;
+
+          #pragma unroll
+          for(int k = 0; k < 8; ++k)
+            acc |= v[k].x & v[k].y & v[k].z & v[k].w;
+
+          if (acc == 0x12345678u)              // never: keeps the loads
+            dst[threadIdx.x] = v[0];
+        }
+        else
+        {
+          #pragma unroll
+          for(int k = 0; k < 8; ++k)
+            dst[peer * (bytes / 16) + first + threadIdx.x + k * THREADS] = v[k];
+        }
+      }
+      else if (mode == 1)
+      {
       }
       else
       {
@@ -67,7 +85,14 @@ namespace
 }
 
 // bytes: a multiple of 16.  gbps: the bus bandwidth the copy is paced to (bytes * peers / duration), 0 = as fast as it goes.
+extern "C" int datum_farm_standin_gather_mode(void *gathered, void const *payload, size_t bytes, int peers, int workgroups, double gbps, int mode, void *stream);
+
 extern "C" int datum_farm_standin_gather(void *gathered, void const *payload, size_t bytes, int peers, int workgroups, double gbps, void *stream)
+{
+  return datum_farm_standin_gather_mode(gathered, payload, bytes, peers, workgroups, gbps, 0, stream);
+}
+
+extern "C" int datum_farm_standin_gather_mode(void *gathered, void const *payload, size_t bytes, int peers, int workgroups, double gbps, int mode, void *stream)
 {
   if (!gathered || !payload || (bytes & 15) || peers < 1 || workgroups < 1)
     return -1;
@@ -79,7 +104,7 @@ extern "C" int datum_farm_standin_gather(void *gathered, void const *payload, si
   double const mine = (double)(chunks * peers) / workgroups;
   float const ticks = gbps > 0 ? (float)(seconds * 1e8 / mine) : 0.0f;
 
-  hipLaunchKernelGGL(standin_kernel, dim3(workgroups), dim3(THREADS), 0, (hipStream_t)stream, (uint4*)gathered, (uint4 const*)payload, bytes, peers, ticks);
+  hipLaunchKernelGGL(standin_kernel, dim3(workgroups), dim3(THREADS), 0, (hipStream_t)stream, (uint4*)gathered, (uint4 const*)payload, bytes, peers, ticks, mode);
 
   return (int)hipGetLastError();
 }

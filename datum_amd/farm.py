@@ -121,8 +121,9 @@ class TileGather:
 
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdatum_farm_standin.so")
             self.standin_lib = ctypes.CDLL(path)      # fails loudly when the library was not built
-            self.standin_lib.datum_farm_standin_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
-                                                                   ctypes.c_double, ctypes.c_void_p]
+            self.standin_lib.datum_farm_standin_gather_mode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                                                        ctypes.c_double, ctypes.c_int, ctypes.c_void_p]
+            self.standin_mode = int(os.environ.get("DATUM_STANDIN_MODE", "0"))    # tools/gather_overhead.sh: 1 resident only, 2 reads only, 3 writes only
         self.world = world
         self.collective = world > 1 or force_collective
         self.device = torch.device(device)
@@ -174,9 +175,9 @@ class TileGather:
                         dist.all_gather_into_tensor(self.gathered[s], self.payload[s])
                     elif self.standin_lib is not None:
                         n = self.payload[s].numel()
-                        rc = self.standin_lib.datum_farm_standin_gather(self.gathered[s][n:].data_ptr(), self.payload[s].data_ptr(),
-                                                                        n * self.payload[s].element_size(), self.standin, self.standin_workgroups,
-                                                                        self.standin_gbps, self.comm.cuda_stream)
+                        rc = self.standin_lib.datum_farm_standin_gather_mode(self.gathered[s][n:].data_ptr(), self.payload[s].data_ptr(),
+                                                                             n * self.payload[s].element_size(), self.standin, self.standin_workgroups,
+                                                                             self.standin_gbps, self.standin_mode, self.comm.cuda_stream)
                         assert rc == 0, f"datum_farm_standin_gather: {rc}"
                     else:
                         n = self.payload[s].numel()

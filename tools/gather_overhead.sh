@@ -3,7 +3,7 @@
 # here; in its place (bench.py --standin-peers 7) a kernel of W workgroups stays resident on the communication stream for as
 # long as a collective at G GB/s of bus bandwidth would and writes 7 peers' payloads into the gathered buffer.
 STEPS=${STEPS:-20}; WARM=${WARM:-5}
-run() { python bench.py --steps $STEPS --warmup $WARM --cpu-seconds 0 --no-frame "$@" 2>/dev/null | python3 -c '
+run() { python bench.py --steps ${STEPS:-20} --warmup ${WARM:-5} --cpu-seconds 0 --no-frame "$@" 2>/dev/null | python3 -c '
 import json,sys
 for l in sys.stdin:
     if l.startswith("{"):
@@ -24,6 +24,10 @@ run --standin-peers 7 --payload xyz32 --standin-workgroups 32 --standin-gbps 300
 run --force-collective --payload xyz32
 run --force-collective --payload xyz32 --gather-every 1
 done
+echo "== which part of the stand-in costs the step (32 workgroups, paced to 300 GB/s = 1.18 ms resident, xyz32)"
+for m in 0 1 2 3; do echo "  mode $m (0 copy, 1 resident only, 2 reads only, 3 writes only):"; DATUM_STANDIN_MODE=$m run --standin-peers 7 --payload xyz32 --standin-workgroups 32 --standin-gbps 300; done
+echo "  mode 1 with 256 workgroups:"; DATUM_STANDIN_MODE=1 run --standin-peers 7 --payload xyz32 --standin-workgroups 256 --standin-gbps 300
+echo "  200-step batches:"; STEPS=200 WARM=20 run; STEPS=200 WARM=20 run --standin-peers 7 --payload xyz32 --standin-workgroups 32 --standin-gbps 300
 echo "== configs[3] share: 2048^2 x 1"
 run --resolution 2048 --cascades 1
 run --resolution 2048 --cascades 1 --standin-peers 7 --standin-workgroups 32 --standin-gbps 300
