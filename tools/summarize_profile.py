@@ -3,7 +3,9 @@
 import csv, glob, os, sys, collections
 d = sys.argv[1]
 def short(k):
-    k = k.split("(")[0]
+    import re
+    k = re.sub(r"\(ocean::GenLayout\)", "", k)       # ocean_gen_kernel<(ocean::GenLayout)0>
+    k = re.sub(r"\([^()]*\)\s*$", "", k)             # the parameter list
     for a, b in (("void ocean::", ""), ("ocean::", ""), ("_kernel", "")):
         k = k.replace(a, b)
     return k[:40]
