@@ -274,7 +274,12 @@ namespace ocean
   // 134-154 registers instead of 86 and spills -- measured 17.7 against 16.3 us; a persistent loop, 3 or 4 workgroups
   // per CU: 17.1 / 18.1 us; a 1024-thread workgroup per CU sampling a 64^2 map from LDS: 24.5 us.  profiles/r03_gen_experiments.txt)
 
+#ifndef OCEAN_GEN_WAVES_PER_SIMD
+#define OCEAN_GEN_WAVES_PER_SIMD 5   // the register budget the kernel is compiled for (96): 101 without it, one wave per SIMD fewer
+#endif
+
   template<int LAYOUT>
+  __attribute__((amdgpu_waves_per_eu(OCEAN_GEN_WAVES_PER_SIMD, OCEAN_GEN_WAVES_PER_SIMD)))
   __global__ void __launch_bounds__(GEN_THREADS) ocean_gen_kernel(GenArgs g)
   {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -382,6 +387,8 @@ namespace ocean
 
     int o00[2], o10[2], o01[2], o11[2];       // byte offsets of the four corners' displacement texels
 
+    bool near = false;                        // some weight other than w00 is not zero
+
     #pragma unroll
     for(int i = 0; i < 2; ++i)
     {
@@ -398,6 +405,8 @@ namespace ocean
       bool const wantx = ax[i] != 0.0f, wanty = ay[i] != 0.0f;
 
       o00[i] = r0 + c0; o10[i] = wantx ? r0 + c1 : -256; o01[i] = wanty ? r1 + c0 : -256; o11[i] = (wantx && wanty) ? r1 + c1 : -256;
+
+      near = near || wantx || wanty;
     }
 
     OCEAN_STAMP(1);
@@ -410,18 +419,19 @@ namespace ocean
     float4 a00[2], a10[2], a01[2], a11[2];      // displacement layer
     float4 b00[2], b10[2], b01[2], b11[2];      // normal layer
 
-#ifdef OCEAN_GEN_ABLATE_LOADS      // timing-only builds (tools/): no map fetches
-    #pragma unroll
-    for(int i = 0; i < 2; ++i)
-    {
-      a00[i] = a10[i] = a01[i] = a11[i] = make_float4(0.01f * (float)(o00[i] & 7), 0.02f, 0.03f * (float)(o01[i] & 3), 0.0f);
-      b00[i] = b10[i] = b01[i] = b11[i] = make_float4(0.0f, 0.1f, 0.9f, 0.0f);
-    }
-#else
     // (a corner's normal sits in the 128-byte line of its displacement: fetched right behind it, it finds the line in L1 --
     // eight displacement fetches of 64 lanes later the line may have left the cache again)
+#ifdef OCEAN_GEN_ABLATE_LOADS      // timing-only builds (tools/): no map fetches
+    #define OCEAN_GEN_FETCH_A(C) a##C[i] = make_float4(0.01f * (float)(o##C[i] & 7), 0.02f, 0.03f * (float)(o##C[i] & 3), 0.0f)
+    #define OCEAN_GEN_FETCH_B(C) b##C[i] = make_float4(0.0f, 0.1f, 0.9f, 0.0f)
+#else
     #define OCEAN_GEN_FETCH_A(C) a##C[i] = buf_load_f32x4_aux<0>(rmap, o##C[i], 0)
     #define OCEAN_GEN_FETCH_B(C) b##C[i] = buf_load_f32x4_aux<0>(rmap, o##C[i] + MAP_GROUP * 16, 0)
+#endif
+
+    #define OCEAN_GEN_BLEND(T, C) pfma(w11, v2{ T##11[0].C, T##11[1].C }, pfma(w01, v2{ T##01[0].C, T##01[1].C }, pfma(w10, v2{ T##10[0].C, T##10[1].C }, w00 * v2{ T##00[0].C, T##00[1].C })))
+
+    p3 displacement;
 
     if (shaded)
     {
@@ -433,8 +443,10 @@ namespace ocean
         OCEAN_GEN_FETCH_A(01); OCEAN_GEN_FETCH_B(01);
         OCEAN_GEN_FETCH_A(11); OCEAN_GEN_FETCH_B(11);
       }
+
+      displacement = { OCEAN_GEN_BLEND(a, x), OCEAN_GEN_BLEND(a, y), OCEAN_GEN_BLEND(a, z) };
     }
-    else
+    else if (__builtin_amdgcn_ballot_w64(near) != 0)
     {
       #pragma unroll
       for(int i = 0; i < 2; ++i)
@@ -444,20 +456,27 @@ namespace ocean
         OCEAN_GEN_FETCH_A(01);
         OCEAN_GEN_FETCH_A(11);
       }
+
+      displacement = { OCEAN_GEN_BLEND(a, x), OCEAN_GEN_BLEND(a, y), OCEAN_GEN_BLEND(a, z) };
+    }
+    else
+    {
+      // every ray of the wave lands beyond |coordinate| = 2^23 texels along both axes (the rays above the horizon): one
+      // texel per vertex, its weight (1 - 0) * (1 - 0); the other three fetches would only occupy the texture path
+      #pragma unroll
+      for(int i = 0; i < 2; ++i)
+        OCEAN_GEN_FETCH_A(00);
+
+      displacement = { w00 * v2{ a00[0].x, a00[1].x }, w00 * v2{ a00[0].y, a00[1].y }, w00 * v2{ a00[0].z, a00[1].z } };
     }
 
     #undef OCEAN_GEN_FETCH_A
     #undef OCEAN_GEN_FETCH_B
-#endif
 
     OCEAN_WAIT_LOADS();
     OCEAN_STAMP(2);
 
-    //-- bilinear blend and shading frame (gen.comp:101-120), FMAs ------------------------------------------------
-
-    #define OCEAN_GEN_BLEND(T, C) pfma(w11, v2{ T##11[0].C, T##11[1].C }, pfma(w01, v2{ T##01[0].C, T##01[1].C }, pfma(w10, v2{ T##10[0].C, T##10[1].C }, w00 * v2{ T##00[0].C, T##00[1].C })))
-
-    p3 const displacement = { OCEAN_GEN_BLEND(a, x), OCEAN_GEN_BLEND(a, y), OCEAN_GEN_BLEND(a, z) };
+    //-- shading frame (gen.comp:101-120), FMAs --------------------------------------------------------------------
 
     p3 const planen = { splat(p.plane[0]), splat(p.plane[1]), splat(p.plane[2]) };
 
