@@ -81,8 +81,12 @@ namespace ocean
 #endif
 
   // a workgroup's tile is 32 x 16 vertices, a wave owns 32 x 4 of them (a "wave tile"), a thread (x, y) and (x + 16, y)
+#ifndef OCEAN_GEN_PHASES
+#define OCEAN_GEN_PHASES 1           // sets of four rows per wave (2: software-pipelined, 32 x 32 vertices per workgroup)
+#endif
+
   constexpr int GEN_TILE_X = 32;
-  constexpr int GEN_TILE_Y = 16;
+  constexpr int GEN_TILE_Y = 16 * OCEAN_GEN_PHASES;
   constexpr int GEN_THREADS = 256;
   constexpr size_t GEN_LDS = (size_t)GEN_THREADS * 2 * 3 * sizeof(float4);
 
@@ -289,6 +293,8 @@ namespace ocean
 #endif
     OCEAN_STAMP(0);
 
+    constexpr int PH = OCEAN_GEN_PHASES;
+
     datum_ocean_set const &p = g.set;
     GenFrame const &f = g.frame;
 
@@ -315,238 +321,262 @@ namespace ocean
     int const tilex = tile % g.tilesx, tiley = tile / g.tilesx;
 
     int const x0 = tilex * GEN_TILE_X;
-    int const y0 = tiley * GEN_TILE_Y + 4 * wave;                  // first of this wave's four rows
+    int const ywave = tiley * GEN_TILE_Y + 4 * PH * wave;          // first of this wave's 4 * PH rows
 
     int const xa = x0 + (lane & 15);
-    int const yy = y0 + (lane >> 4);
-
-    //-- view ray, plane hit, swell phase: the shader's expressions and roundings (gen.comp:81-99) ----------------
-
-    v2 const xx = { (float)xa, (float)(xa + 16) };
-
-    v2 const u = (div_exact(2.0f * xx, splat(f.sxm1)) - 1.0f) * f.margin;
-
-    // (one row per thread: its v is the first half of a packed division whose second half repeats it)
-    float const v = ((1.0f - div_exact(splat(2.0f * (float)yy), splat(f.sym1))) * f.margin).x;
 
     float const *ip = p.invproj;
-
-    p3 viewvec = { ((ip[0] * u + ip[1] * v) + f.viewz[0]) + f.vieww[0],
-                   ((ip[4] * u + ip[5] * v) + f.viewz[1]) + f.vieww[1],
-                   ((ip[8] * u + ip[9] * v) + f.viewz[2]) + f.vieww[2] };
-
-    v2 const len = sqrt_exact(dot3(viewvec, viewvec));
-    v2 const rlen = refined_rcp(len);
-
-    p3 const worlddir = rotate(p.camera_real, p3{ div_exact(viewvec.x, len, rlen), div_exact(viewvec.y, len, rlen), div_exact(viewvec.z, len, rlen) });
-
-    v2 const costheta = worlddir.x * f.negplane[0] + worlddir.y * f.negplane[1] + worlddir.z * f.negplane[2];
-
-    v2 const hit = div_exact(splat(f.cameraheight), costheta);
-
-    v2 const dist = { (costheta.x > 0) ? hit.x : 1e6f, (costheta.y > 0) ? hit.y : 1e6f };
-
-    v2 const basex = f.camerapos[0] + dist * worlddir.x;
-    v2 const basey = f.camerapos[1] + dist * worlddir.y;
-
-    v2 const theta = f.frequency * (p.swelldirection[0] * basex + p.swelldirection[1] * basey) + p.swellphase;
-
-    v2 st, ct;
-    sincos_phase2(theta, st, ct);
-
-    p3 const position = { basex + f.gx * ct, basey + f.gy * ct, f.basez + p.swellamplitude * st };
-
-    v2 cl = dist * p.smoothing - 0.35f;
-
-    v2 smoothing;       // pow(clamp(cl, 0, 1), 0.2): 0 -> 0, 1 -> 1 exactly
-
-    #pragma unroll
-    for(int i = 0; i < 2; ++i)
-      smoothing[i] = __builtin_amdgcn_exp2f(0.2f * __builtin_amdgcn_logf(__builtin_amdgcn_fmed3f(cl[i], 0.0f, 1.0f)));
-
-    //-- texture(sampler2DArray, REPEAT, linear, lod 0) of both layers at (position.xy * scale): texel centres at (i + 0.5) / N ----
-
-    v2 const fx = (position.x * p.scale) * f.fn - 0.5f;
-    v2 const fy = (position.y * p.scale) * f.fn - 0.5f;
-
-    v2 const flx = pfloor(fx), fly = pfloor(fy);
-
-    v2 const ax = fx - flx, ay = fy - fly;
-
-    // floor(coordinate) mod N: N is a power of two, so coordinate / N, its fractional part and the product with N are exact
-    v2 const wx = flx * f.rfn, wy = fly * f.rfn;
-    v2 const mx = v2{ __builtin_amdgcn_fractf(wx.x), __builtin_amdgcn_fractf(wx.y) } * f.fn;
-    v2 const my = v2{ __builtin_amdgcn_fractf(wy.x), __builtin_amdgcn_fractf(wy.y) } * f.fn;
-
-    v2 const bx = 1.0f - ax, by = 1.0f - ay;
-    v2 const w00 = bx * by, w10 = ax * by, w01 = bx * ay, w11 = ax * ay;
 
     TexelIndex<LAYOUT> const texel(g.N);
 
     int const nmask = g.N - 1;
 
-    int o00[2], o10[2], o01[2], o11[2];       // byte offsets of the four corners' displacement texels
-
-    bool near = false;                        // some weight other than w00 is not zero
-
-    #pragma unroll
-    for(int i = 0; i < 2; ++i)
-    {
-      int const i0 = (int)mx[i], j0 = (int)my[i];
-
-      int const i1 = (i0 + 1) & nmask, j1 = (j0 + 1) & nmask;
-
-      int const c0 = texel.column(i0) * 16, c1 = texel.column(i1) * 16;
-      int const r0 = texel.row(j0) * 16, r1 = texel.row(j1) * 16;
-
-      // A zero weight along an axis (beyond |coordinate| = 2^23 texels: every ray above the horizon): the second texel of
-      // that axis is not needed (0 * finite adds nothing).  Its offset is pushed out of the buffer's range: zeros come
-      // back without a memory access, and no branch -- hence no wait -- separates the fetches.
-      bool const wantx = ax[i] != 0.0f, wanty = ay[i] != 0.0f;
-
-      o00[i] = r0 + c0; o10[i] = wantx ? r0 + c1 : -256; o01[i] = wanty ? r1 + c0 : -256; o11[i] = (wantx && wanty) ? r1 + c1 : -256;
-
-      near = near || wantx || wanty;
-    }
-
-    OCEAN_STAMP(1);
-
     __amdgpu_buffer_rsrc_t const rmap = make_rsrc(g.map, (size_t)2 * g.N * g.N * sizeof(float4));
 
-    // wave-uniform: only a wave with a vertex inside the smoothing distance needs the normal layer and the Gerstner frame
-    bool const shaded = __builtin_amdgcn_ballot_w64(smoothing.x != 1.0f || smoothing.y != 1.0f) != 0;
+    // per phase (PH = 2: two sets of four rows per wave; the second set's ray arithmetic runs under the first set's fetches,
+    // the first set's shading under the second set's fetches)
+    p3 position[PH];
+    v2 w00[PH], w10[PH], w01[PH], w11[PH], smoothing[PH], st[PH], ct[PH];
+    int o00[PH][2], o10[PH][2], o01[PH][2], o11[PH][2];       // byte offsets of the four corners' displacement texels
+    bool shaded[PH], near[PH];
+    float4 a00[PH][2], a10[PH][2], a01[PH][2], a11[PH][2];      // displacement layer
+    float4 b00[PH][2], b10[PH][2], b01[PH][2], b11[PH][2];      // normal layer
 
-    float4 a00[2], a10[2], a01[2], a11[2];      // displacement layer
-    float4 b00[2], b10[2], b01[2], b11[2];      // normal layer
+    #pragma unroll
+    for(int ph = 0; ph < PH; ++ph)
+    {
+      int const yy = ywave + 4 * ph + (lane >> 4);
 
-    // (a corner's normal sits in the 128-byte line of its displacement: fetched right behind it, it finds the line in L1 --
-    // eight displacement fetches of 64 lanes later the line may have left the cache again)
+      //-- view ray, plane hit, swell phase: the shader's expressions and roundings (gen.comp:81-99) ----------------
+
+      v2 const xx = { (float)xa, (float)(xa + 16) };
+
+      v2 const u = (div_exact(2.0f * xx, splat(f.sxm1)) - 1.0f) * f.margin;
+
+      // (one row per thread: its v is the first half of a packed division whose second half repeats it)
+      float const v = ((1.0f - div_exact(splat(2.0f * (float)yy), splat(f.sym1))) * f.margin).x;
+
+      p3 viewvec = { ((ip[0] * u + ip[1] * v) + f.viewz[0]) + f.vieww[0],
+                     ((ip[4] * u + ip[5] * v) + f.viewz[1]) + f.vieww[1],
+                     ((ip[8] * u + ip[9] * v) + f.viewz[2]) + f.vieww[2] };
+
+      v2 const len = sqrt_exact(dot3(viewvec, viewvec));
+      v2 const rlen = refined_rcp(len);
+
+      p3 const worlddir = rotate(p.camera_real, p3{ div_exact(viewvec.x, len, rlen), div_exact(viewvec.y, len, rlen), div_exact(viewvec.z, len, rlen) });
+
+      v2 const costheta = worlddir.x * f.negplane[0] + worlddir.y * f.negplane[1] + worlddir.z * f.negplane[2];
+
+      v2 const hit = div_exact(splat(f.cameraheight), costheta);
+
+      v2 const dist = { (costheta.x > 0) ? hit.x : 1e6f, (costheta.y > 0) ? hit.y : 1e6f };
+
+      v2 const basex = f.camerapos[0] + dist * worlddir.x;
+      v2 const basey = f.camerapos[1] + dist * worlddir.y;
+
+      v2 const theta = f.frequency * (p.swelldirection[0] * basex + p.swelldirection[1] * basey) + p.swellphase;
+
+      sincos_phase2(theta, st[ph], ct[ph]);
+
+      position[ph] = { basex + f.gx * ct[ph], basey + f.gy * ct[ph], f.basez + p.swellamplitude * st[ph] };
+
+      v2 cl = dist * p.smoothing - 0.35f;
+
+      #pragma unroll
+      for(int i = 0; i < 2; ++i)       // pow(clamp(cl, 0, 1), 0.2): 0 -> 0, 1 -> 1 exactly
+        smoothing[ph][i] = __builtin_amdgcn_exp2f(0.2f * __builtin_amdgcn_logf(__builtin_amdgcn_fmed3f(cl[i], 0.0f, 1.0f)));
+
+      //-- texture(sampler2DArray, REPEAT, linear, lod 0) of both layers at (position.xy * scale): texel centres at (i + 0.5) / N ----
+
+      v2 const fx = (position[ph].x * p.scale) * f.fn - 0.5f;
+      v2 const fy = (position[ph].y * p.scale) * f.fn - 0.5f;
+
+      v2 const flx = pfloor(fx), fly = pfloor(fy);
+
+      v2 const ax = fx - flx, ay = fy - fly;
+
+      // floor(coordinate) mod N: N is a power of two, so coordinate / N, its fractional part and the product with N are exact
+      v2 const wx = flx * f.rfn, wy = fly * f.rfn;
+      v2 const mx = v2{ __builtin_amdgcn_fractf(wx.x), __builtin_amdgcn_fractf(wx.y) } * f.fn;
+      v2 const my = v2{ __builtin_amdgcn_fractf(wy.x), __builtin_amdgcn_fractf(wy.y) } * f.fn;
+
+      v2 const bx = 1.0f - ax, by = 1.0f - ay;
+
+      w00[ph] = bx * by; w10[ph] = ax * by; w01[ph] = bx * ay; w11[ph] = ax * ay;
+
+      near[ph] = false;                        // some weight other than w00 is not zero
+
+      #pragma unroll
+      for(int i = 0; i < 2; ++i)
+      {
+        int const i0 = (int)mx[i], j0 = (int)my[i];
+
+        int const i1 = (i0 + 1) & nmask, j1 = (j0 + 1) & nmask;
+
+        int const c0 = texel.column(i0) * 16, c1 = texel.column(i1) * 16;
+        int const r0 = texel.row(j0) * 16, r1 = texel.row(j1) * 16;
+
+        // A zero weight along an axis (beyond |coordinate| = 2^23 texels: every ray above the horizon): the second texel of
+        // that axis is not needed (0 * finite adds nothing).  Its offset is pushed out of the buffer's range: zeros come
+        // back without a memory access, and no branch -- hence no wait -- separates the fetches.
+        bool const wantx = ax[i] != 0.0f, wanty = ay[i] != 0.0f;
+
+        o00[ph][i] = r0 + c0; o10[ph][i] = wantx ? r0 + c1 : -256; o01[ph][i] = wanty ? r1 + c0 : -256; o11[ph][i] = (wantx && wanty) ? r1 + c1 : -256;
+
+        near[ph] = near[ph] || wantx || wanty;
+      }
+
+      near[ph] = __builtin_amdgcn_ballot_w64(near[ph]) != 0;
+
+      OCEAN_STAMP(1);
+
+      // wave-uniform: only a wave with a vertex inside the smoothing distance needs the normal layer and the Gerstner frame
+      shaded[ph] = __builtin_amdgcn_ballot_w64(smoothing[ph].x != 1.0f || smoothing[ph].y != 1.0f) != 0;
+
+      // (a corner's normal sits in the 128-byte line of its displacement: fetched right behind it, it finds the line in L1 --
+      // eight displacement fetches of 64 lanes later the line may have left the cache again)
 #ifdef OCEAN_GEN_ABLATE_LOADS      // timing-only builds (tools/): no map fetches
-    #define OCEAN_GEN_FETCH_A(C) a##C[i] = make_float4(0.01f * (float)(o##C[i] & 7), 0.02f, 0.03f * (float)(o##C[i] & 3), 0.0f)
-    #define OCEAN_GEN_FETCH_B(C) b##C[i] = make_float4(0.0f, 0.1f, 0.9f, 0.0f)
+      #define OCEAN_GEN_FETCH_A(C) a##C[ph][i] = make_float4(0.01f * (float)(o##C[ph][i] & 7), 0.02f, 0.03f * (float)(o##C[ph][i] & 3), 0.0f)
+      #define OCEAN_GEN_FETCH_B(C) b##C[ph][i] = make_float4(0.0f, 0.1f, 0.9f, 0.0f)
 #else
-    #define OCEAN_GEN_FETCH_A(C) a##C[i] = buf_load_f32x4_aux<0>(rmap, o##C[i], 0)
-    #define OCEAN_GEN_FETCH_B(C) b##C[i] = buf_load_f32x4_aux<0>(rmap, o##C[i] + MAP_GROUP * 16, 0)
+      #define OCEAN_GEN_FETCH_A(C) a##C[ph][i] = buf_load_f32x4_aux<0>(rmap, o##C[ph][i], 0)
+      #define OCEAN_GEN_FETCH_B(C) b##C[ph][i] = buf_load_f32x4_aux<0>(rmap, o##C[ph][i] + MAP_GROUP * 16, 0)
 #endif
 
-    #define OCEAN_GEN_BLEND(T, C) pfma(w11, v2{ T##11[0].C, T##11[1].C }, pfma(w01, v2{ T##01[0].C, T##01[1].C }, pfma(w10, v2{ T##10[0].C, T##10[1].C }, w00 * v2{ T##00[0].C, T##00[1].C })))
-
-    p3 displacement;
-
-    if (shaded)
-    {
-      #pragma unroll
-      for(int i = 0; i < 2; ++i)
+      if (shaded[ph])
       {
-        OCEAN_GEN_FETCH_A(00); OCEAN_GEN_FETCH_B(00);
-        OCEAN_GEN_FETCH_A(10); OCEAN_GEN_FETCH_B(10);
-        OCEAN_GEN_FETCH_A(01); OCEAN_GEN_FETCH_B(01);
-        OCEAN_GEN_FETCH_A(11); OCEAN_GEN_FETCH_B(11);
+        #pragma unroll
+        for(int i = 0; i < 2; ++i)
+        {
+          OCEAN_GEN_FETCH_A(00); OCEAN_GEN_FETCH_B(00);
+          OCEAN_GEN_FETCH_A(10); OCEAN_GEN_FETCH_B(10);
+          OCEAN_GEN_FETCH_A(01); OCEAN_GEN_FETCH_B(01);
+          OCEAN_GEN_FETCH_A(11); OCEAN_GEN_FETCH_B(11);
+        }
+      }
+      else if (near[ph])
+      {
+        #pragma unroll
+        for(int i = 0; i < 2; ++i)
+        {
+          OCEAN_GEN_FETCH_A(00);
+          OCEAN_GEN_FETCH_A(10);
+          OCEAN_GEN_FETCH_A(01);
+          OCEAN_GEN_FETCH_A(11);
+        }
+      }
+      else
+      {
+        // every ray of the wave lands beyond |coordinate| = 2^23 texels along both axes (the rays above the horizon): one
+        // texel per vertex, its weight (1 - 0) * (1 - 0); the other three fetches would only occupy the texture path
+        #pragma unroll
+        for(int i = 0; i < 2; ++i)
+          OCEAN_GEN_FETCH_A(00);
       }
 
-      displacement = { OCEAN_GEN_BLEND(a, x), OCEAN_GEN_BLEND(a, y), OCEAN_GEN_BLEND(a, z) };
-    }
-    else if (__builtin_amdgcn_ballot_w64(near) != 0)
-    {
-      #pragma unroll
-      for(int i = 0; i < 2; ++i)
-      {
-        OCEAN_GEN_FETCH_A(00);
-        OCEAN_GEN_FETCH_A(10);
-        OCEAN_GEN_FETCH_A(01);
-        OCEAN_GEN_FETCH_A(11);
-      }
+      #undef OCEAN_GEN_FETCH_A
+      #undef OCEAN_GEN_FETCH_B
 
-      displacement = { OCEAN_GEN_BLEND(a, x), OCEAN_GEN_BLEND(a, y), OCEAN_GEN_BLEND(a, z) };
+      if (PH > 1)
+        __builtin_amdgcn_sched_barrier(0);       // the next set's arithmetic stays BEHIND these fetches
     }
-    else
-    {
-      // every ray of the wave lands beyond |coordinate| = 2^23 texels along both axes (the rays above the horizon): one
-      // texel per vertex, its weight (1 - 0) * (1 - 0); the other three fetches would only occupy the texture path
-      #pragma unroll
-      for(int i = 0; i < 2; ++i)
-        OCEAN_GEN_FETCH_A(00);
-
-      displacement = { w00 * v2{ a00[0].x, a00[1].x }, w00 * v2{ a00[0].y, a00[1].y }, w00 * v2{ a00[0].z, a00[1].z } };
-    }
-
-    #undef OCEAN_GEN_FETCH_A
-    #undef OCEAN_GEN_FETCH_B
 
     OCEAN_WAIT_LOADS();
     OCEAN_STAMP(2);
 
-    //-- shading frame (gen.comp:101-120), FMAs --------------------------------------------------------------------
-
-    p3 const planen = { splat(p.plane[0]), splat(p.plane[1]), splat(p.plane[2]) };
-
-    p3 tbn2;
-
-    if (shaded)
-    {
-      p3 const dn = { OCEAN_GEN_BLEND(b, x), OCEAN_GEN_BLEND(b, y), OCEAN_GEN_BLEND(b, z) };
-
-      // tbn[2] = normalize(-normal.xy, 1 - normal.z), tbn[0] = normalize(1 - tangent.x, -tangent.y, tangent.z), tbn[1] = tbn[0] x tbn[2]
-      p3 const t2 = normalize3(p3{ -f.nx * ct, -f.ny * ct, pfma(-f.nz, st, 1.0f) });
-      p3 const t0 = normalize3(p3{ pfma(-f.tx, st, 1.0f), -f.ty * st, f.tz * ct });
-      p3 const t1 = { t0.y * t2.z - t0.z * t2.y, t0.z * t2.x - t0.x * t2.z, t0.x * t2.y - t0.y * t2.x };
-
-      // tbn * displacementnormal, mixed towards the plane normal with the distance smoothing
-      p3 const tn = { pfma(dn.z, t2.x, pfma(dn.y, t1.x, dn.x * t0.x)), pfma(dn.z, t2.y, pfma(dn.y, t1.y, dn.x * t0.y)), pfma(dn.z, t2.z, pfma(dn.y, t1.z, dn.x * t0.z)) };
-
-      v2 const keep = 1.0f - smoothing;
-
-      tbn2 = normalize3(p3{ pfma(keep, tn.x, smoothing * planen.x), pfma(keep, tn.y, smoothing * planen.y), pfma(keep, tn.z, smoothing * planen.z) });
-    }
-    else
-      tbn2 = normalize3(planen);
-
-    #undef OCEAN_GEN_BLEND
-
-    // tbn[0] = normalize((1, 0, 0) - tbn[2].x * tbn[2])
-    p3 const tbn0 = normalize3(p3{ pfma(-tbn2.x, tbn2.x, 1.0f), -tbn2.x * tbn2.y, -tbn2.x * tbn2.z });
-
-    OCEAN_STAMP(3);
-
-    //-- Mesh::Vertex { position3, texcoord2, normal3, tangent4 } = 48 bytes (src/renderer/mesh.h:20-26) -----------
-    // The wave's 4 rows x 32 vertices = 4 x 96 float4 go through its 6 KB of LDS: lane i then stores float4 number
-    // i, 64 + i, ... 320 + i of the wave's 384 (three 16-byte stores per vertex at a 48-byte stride touch every line three times).
-
-    v2 const px = position.x - displacement.x, py = position.y - displacement.y, pz = position.z + displacement.z;
-    v2 const tu = 0.1f * position.x, tv = 0.1f * position.y;
-
     float4 *mine = reinterpret_cast<float4*>(smem) + 384 * wave;
 
     #pragma unroll
-    for(int i = 0; i < 2; ++i)
+    for(int ph = 0; ph < PH; ++ph)
     {
-      float4 *vtx = mine + 3 * ((lane >> 4) * 32 + 16 * i + (lane & 15));
+      //-- bilinear blend and shading frame (gen.comp:101-120), FMAs ------------------------------------------------
 
-      vtx[0] = make_float4(px[i], py[i], pz[i], tu[i]);
-      vtx[1] = make_float4(tv[i], tbn2.x[i], tbn2.y[i], tbn2.z[i]);
-      vtx[2] = make_float4(tbn0.x[i], tbn0.y[i], tbn0.z[i], -1.0f);
-    }
+      #define OCEAN_GEN_BLEND(T, C) pfma(w11[ph], v2{ T##11[ph][0].C, T##11[ph][1].C }, pfma(w01[ph], v2{ T##01[ph][0].C, T##01[ph][1].C }, pfma(w10[ph], v2{ T##10[ph][0].C, T##10[ph][1].C }, w00[ph] * v2{ T##00[ph][0].C, T##00[ph][1].C })))
 
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      p3 displacement;
 
-    int const rowlen = min(GEN_TILE_X, g.sizex - x0) * 3;                                // float4 of this tile in one mesh row
+      if (shaded[ph] || near[ph])
+        displacement = { OCEAN_GEN_BLEND(a, x), OCEAN_GEN_BLEND(a, y), OCEAN_GEN_BLEND(a, z) };
+      else
+        displacement = { w00[ph] * v2{ a00[ph][0].x, a00[ph][1].x }, w00[ph] * v2{ a00[ph][0].y, a00[ph][1].y }, w00[ph] * v2{ a00[ph][0].z, a00[ph][1].z } };
 
-    // (the wave's part of the address is uniform: a scalar base and a 32-bit offset per lane)
-    float4 *out = reinterpret_cast<float4*>(g.vertices) + ((size_t)y0 * g.sizex + x0) * 3;
+      p3 const planen = { splat(p.plane[0]), splat(p.plane[1]), splat(p.plane[2]) };
 
-    #pragma unroll
-    for(int k = 0; k < 6; ++k)
-    {
-      int const j = 64 * k + lane;
-      int const r = j / 96, c = j % 96;
+      p3 tbn2;
+
+      if (shaded[ph])
+      {
+        p3 const dn = { OCEAN_GEN_BLEND(b, x), OCEAN_GEN_BLEND(b, y), OCEAN_GEN_BLEND(b, z) };
+
+        // tbn[2] = normalize(-normal.xy, 1 - normal.z), tbn[0] = normalize(1 - tangent.x, -tangent.y, tangent.z), tbn[1] = tbn[0] x tbn[2]
+        p3 const t2 = normalize3(p3{ -f.nx * ct[ph], -f.ny * ct[ph], pfma(-f.nz, st[ph], 1.0f) });
+        p3 const t0 = normalize3(p3{ pfma(-f.tx, st[ph], 1.0f), -f.ty * st[ph], f.tz * ct[ph] });
+        p3 const t1 = { t0.y * t2.z - t0.z * t2.y, t0.z * t2.x - t0.x * t2.z, t0.x * t2.y - t0.y * t2.x };
+
+        // tbn * displacementnormal, mixed towards the plane normal with the distance smoothing
+        p3 const tn = { pfma(dn.z, t2.x, pfma(dn.y, t1.x, dn.x * t0.x)), pfma(dn.z, t2.y, pfma(dn.y, t1.y, dn.x * t0.y)), pfma(dn.z, t2.z, pfma(dn.y, t1.z, dn.x * t0.z)) };
+
+        v2 const keep = 1.0f - smoothing[ph];
+
+        tbn2 = normalize3(p3{ pfma(keep, tn.x, smoothing[ph] * planen.x), pfma(keep, tn.y, smoothing[ph] * planen.y), pfma(keep, tn.z, smoothing[ph] * planen.z) });
+      }
+      else
+        tbn2 = normalize3(planen);
+
+      #undef OCEAN_GEN_BLEND
+
+      // tbn[0] = normalize((1, 0, 0) - tbn[2].x * tbn[2])
+      p3 const tbn0 = normalize3(p3{ pfma(-tbn2.x, tbn2.x, 1.0f), -tbn2.x * tbn2.y, -tbn2.x * tbn2.z });
+
+      OCEAN_STAMP(3);
+
+      //-- Mesh::Vertex { position3, texcoord2, normal3, tangent4 } = 48 bytes (src/renderer/mesh.h:20-26) -----------
+      // The wave's 4 rows x 32 vertices = 4 x 96 float4 go through its 6 KB of LDS: lane i then stores float4 number
+      // i, 64 + i, ... 320 + i of the wave's 384 (three 16-byte stores per vertex at a 48-byte stride touch every line three times).
+
+      v2 const px = position[ph].x - displacement.x, py = position[ph].y - displacement.y, pz = position[ph].z + displacement.z;
+      v2 const tu = 0.1f * position[ph].x, tv = 0.1f * position[ph].y;
+
+      #pragma unroll
+      for(int i = 0; i < 2; ++i)
+      {
+        float4 *vtx = mine + 3 * ((lane >> 4) * 32 + 16 * i + (lane & 15));
+
+        vtx[0] = make_float4(px[i], py[i], pz[i], tu[i]);
+        vtx[1] = make_float4(tv[i], tbn2.x[i], tbn2.y[i], tbn2.z[i]);
+        vtx[2] = make_float4(tbn0.x[i], tbn0.y[i], tbn0.z[i], -1.0f);
+      }
+
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      int const y0 = ywave + 4 * ph;
+      int const rowlen = min(GEN_TILE_X, g.sizex - x0) * 3;                                // float4 of this tile in one mesh row
+
+      // (the wave's part of the address is uniform: a scalar base and a 32-bit offset per lane)
+      float4 *out = reinterpret_cast<float4*>(g.vertices) + ((size_t)y0 * g.sizex + x0) * 3;
+
+      #pragma unroll
+      for(int k = 0; k < 6; ++k)
+      {
+        int const j = 64 * k + lane;
+        int const r = j / 96, c = j % 96;
 
 #ifdef OCEAN_GEN_ABLATE_STORES     // timing-only builds: the values stay live, nothing is written
-      if (mine[j].w == 123456.789f)
+        if (mine[j].w == 123456.789f)
 #endif
-      if (c < rowlen && y0 + r < g.sizey)
-        out[(unsigned)(r * g.sizex * 3 + c)] = mine[j];
+        if (c < rowlen && y0 + r < g.sizey)
+          out[(unsigned)(r * g.sizex * 3 + c)] = mine[j];
+      }
+
+      if (PH > 1)
+      {
+        // the staging area is written again by the next set
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
     }
 
     OCEAN_STAMP_WHERE();
