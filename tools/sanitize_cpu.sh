@@ -14,4 +14,4 @@ g++ $SAN -std=c++14 -fPIC -ffp-contract=off -fno-fast-math -Wall -shared -o datu
 g++ $SAN -std=c++14 -fPIC -fopenmp -ffp-contract=off -fno-fast-math -Wall -shared -o oracle/liboracle.so oracle/ocean_oracle.cpp
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 OMP_NUM_THREADS=4
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
-  python -m pytest tests/test_host_shim.py tests/test_consumer_contract.py tests/test_oracle_pins.py tests/test_golden_and_abi.py -x -q
+  python -m pytest tests/test_host_shim.py tests/test_consumer_contract.py tests/test_oracle_pins.py tests/test_golden_and_abi.py -x -q -m "not gpu"
