@@ -88,7 +88,10 @@ namespace ocean
   constexpr int GEN_TILE_X = 32;
   constexpr int GEN_TILE_Y = 16 * OCEAN_GEN_PHASES;
   constexpr int GEN_THREADS = 256;
-  constexpr size_t GEN_LDS = (size_t)GEN_THREADS * 2 * 3 * sizeof(float4);
+#ifndef OCEAN_GEN_EXTRA_LDS
+#define OCEAN_GEN_EXTRA_LDS 0         // tools/: bytes of unused LDS per workgroup (limits the workgroups per CU: 160 KB / (24 KB + extra))
+#endif
+  constexpr size_t GEN_LDS = (size_t)GEN_THREADS * 2 * 3 * sizeof(float4) + OCEAN_GEN_EXTRA_LDS;
 
   inline GenFrame make_gen_frame(datum_ocean_set const &p, int N, int sizex, int sizey)
   {
@@ -611,6 +614,9 @@ namespace ocean
       case GEN_BANDED: kernel = reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_BANDED>); break;
       case GEN_PATCHED: kernel = reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_PATCHED>); break;
     }
+
+    if (GEN_LDS > 64 * 1024)       // (tools/ builds only)
+      (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEN_LDS);
 
     int const groups = g.chunk ? ((g.tiles + 8 * g.chunk - 1) / (8 * g.chunk)) * 8 * g.chunk : g.tiles;
 
