@@ -578,7 +578,10 @@ namespace ocean
 
     static constexpr int PER_CU = (LDS * 2 <= (size_t)160 * 1024) ? 2 : 1;                     // persistent workgroups per compute unit (walking)
     static constexpr int FIT = (int)(((size_t)160 * 1024) / LDS);                              // workgroups per CU the LDS allows
-    static constexpr int MIN_WAVES = WALK ? (THREADS / 64) * PER_CU / 4 : (SEQ ? ((THREADS / 64) * (FIT > 4 ? 4 : FIT) + 3) / 4 : 1);   // per SIMD, for __launch_bounds__
+#ifndef OCEAN_ROW_SEQ_MAX_PER_CU
+#define OCEAN_ROW_SEQ_MAX_PER_CU 4
+#endif
+    static constexpr int MIN_WAVES = WALK ? (THREADS / 64) * PER_CU / 4 : (SEQ ? ((THREADS / 64) * (FIT > OCEAN_ROW_SEQ_MAX_PER_CU ? OCEAN_ROW_SEQ_MAX_PER_CU : FIT) + 3) / 4 : 1);   // per SIMD, for __launch_bounds__
 
     static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
   };
