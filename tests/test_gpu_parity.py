@@ -868,3 +868,47 @@ def test_tile_gather_on_device(capi, oracle, torch):
                 assert np.array_equal(farm.view_displacement(got[b].cpu(), N, c, fmt).numpy(), want[b][c]), (b, c)
     finally:
         dist.destroy_process_group()
+
+
+def test_tile_gather_consumer_on_another_stream(capi, oracle, torch):
+    # TileGather.release(): a consumer that reads the gathered buffer on ITS OWN stream (a renderer's upload, a reduction)
+    # must finish before the slot's next collective overwrites the buffer.  The consumer here is slow on purpose (many passes
+    # over the buffer); the stand-in for the collective is the paced copy kernel of bench.py --standin-peers (one GPU).
+    from datum_amd import farm
+
+    N, C, fmt = 256, 2, "xyz32"
+    p = oracle.EXAMPLE
+    code, dtype, _ = farm.PAYLOADS[fmt]
+    stream, consumer = torch.cuda.Stream(), torch.cuda.Stream()
+    with capi.Ocean(N, C) as oc, torch.cuda.stream(stream):
+        oc.set_stream(stream.cuda_stream)
+        for c in range(C):
+            oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c], p["choppiness"])
+            oc.upload_state(c, make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c]))
+        tg = farm.TileGather(farm.payload_numel(N, C, fmt), dtype, "cuda:0", 1, standin_peers=1, standin_workgroups=8, standin_gbps=0.0)
+        nbytes = oc.payload_bytes(code)
+        n = farm.payload_numel(N, C, fmt)
+        sums, wants = [], []
+        for b in range(6):
+            oc.update(DT)
+            oc.displace()
+            buf = tg.acquire()
+            oc.pack_displacement(code, buf.data_ptr(), nbytes)
+            tg.launch()
+            out = tg.result()                                   # the compute stream waits for the collective ...
+            ready = torch.cuda.Event()
+            ready.record(stream)
+            with torch.cuda.stream(consumer):                   # ... the consumer reads on its own stream, slowly
+                consumer.wait_event(ready)
+                acc = torch.zeros((), dtype=torch.float64, device="cuda:0")
+                for _ in range(40):
+                    acc = acc + out[n:2 * n].double().abs().sum()
+                sums.append(acc)
+                tg.release()                                    # the slot's next collective waits for this point
+            wants.append(sum(float(np.abs(oc.read_maps(c)[0, ..., :3].astype(np.float64)).sum()) for c in range(C)) * 40)
+        consumer.synchronize()
+        tg.drain()
+        stream.synchronize()
+        oc.set_stream(None)
+    for b in range(6):
+        assert abs(float(sums[b]) - wants[b]) <= 1e-6 * wants[b], b
