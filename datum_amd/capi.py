@@ -271,6 +271,18 @@ class Ocean:
         self._check(self.lib.datum_ocean_import_semaphore_fd(self.h, fd, ctypes.byref(p)))
         return p.value
 
+    def state_bytes(self):
+        return self.lib.datum_ocean_state_bytes(self.N)
+
+    def park_state(self, cascade, device_ptr, nbytes):
+        """h0 and the phase as advanced so far into caller-owned device memory (device to device); returns the flags to hand back."""
+        flags = I()
+        self._check(self.lib.datum_ocean_park_state(self.h, cascade, P(device_ptr), nbytes, ctypes.byref(flags)))
+        return flags.value
+
+    def resume_state(self, cascade, device_ptr, nbytes, flags):
+        self._check(self.lib.datum_ocean_resume_state(self.h, cascade, P(device_ptr), nbytes, flags))
+
     def read_maps(self, cascade):
         out = np.empty((2, self.N, self.N, 4), np.float32)
         self._check(self.lib.datum_ocean_read_maps(self.h, cascade, _ptr(out)))

@@ -912,3 +912,54 @@ def test_tile_gather_consumer_on_another_stream(capi, oracle, torch):
         oc.set_stream(None)
     for b in range(6):
         assert abs(float(sums[b]) - wants[b]) <= 1e-6 * wants[b], b
+
+
+def test_park_and_resume_state(capi, oracle, torch):
+    # datum_ocean_park_state / resume_state: a cascade's h0 and phase (as advanced so far, queued updates included) into
+    # caller-owned device memory and back, device to device -- another state runs in the cascade meanwhile and the parked
+    # one continues bit-exactly; wrong sizes, cascades and an empty cascade are refused
+    N = 128
+    p = oracle.EXAMPLE
+    h0a, h0b = make_state(oracle, N, 1000), make_state(oracle, N, 1001, 64.0)
+    pa, pb = np.zeros((N, N), np.float32), np.zeros((N, N), np.float32)
+    with capi.Ocean(N, 1) as oc:
+        nbytes = oc.state_bytes()
+        assert nbytes == 12 * N * N
+        slot = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+        with pytest.raises(capi.OceanError) as e:
+            oc.park_state(0, slot.data_ptr(), nbytes)            # nothing uploaded yet
+        assert e.value.code == capi.ESTATE
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        oc.upload_state(0, h0a)
+        for _ in range(3):
+            oc.update(DT)
+            oracle.update(pa, p["wavescale"], DT)
+        oc.displace()
+        oc.update(DT)                                            # queued, not yet applied by a displacement
+        oracle.update(pa, p["wavescale"], DT)
+        for bad in (nbytes - 16, nbytes + 16):
+            with pytest.raises(capi.OceanError) as e:
+                oc.park_state(0, slot.data_ptr(), bad)
+            assert e.value.code == capi.EINVAL
+        with pytest.raises(capi.OceanError) as e:
+            oc.park_state(1, slot.data_ptr(), nbytes)
+        assert e.value.code == capi.EINVAL
+        flags = oc.park_state(0, slot.data_ptr(), nbytes)        # applies the queued update first
+        # another state in the same cascade
+        oc.set_cascade(0, 64.0, p["choppiness"])
+        oc.upload_state(0, h0b)
+        for _ in range(2):
+            oc.update(DT)
+            oracle.update(pb, 64.0, DT)
+        oc.displace()
+        assert np.array_equal(oc.read_state(0), pb)
+        # the first one comes back and continues
+        oc.resume_state(0, slot.data_ptr(), nbytes, flags)
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        assert np.array_equal(oc.read_state(0), pa)
+        oc.update(DT)
+        oracle.update(pa, p["wavescale"], DT)
+        oc.displace()
+        assert np.array_equal(oc.read_state(0), pa)
+        want = oracle.displace(h0a, pa.copy(), p["wavescale"], p["choppiness"], w=oracle.weights(N, reduced=True))
+        assert rmse(oc.read_maps(0), want) < 1e-5
