@@ -47,6 +47,11 @@ def main():
     steep = gen_cases.oceanset(o, N, "pitched_steep", swellphase=1.9)
     out["vertices_600_steep_48x40"] = o.gen(steep, out["maps_600"], 48, 40)
     out["oceanset_steep"] = np.frombuffer(bytes(steep), np.uint8).copy()
+    # a rolled camera over a swell running along y, and a sea level off z = 0 seen from a camera pitched 20 degrees down
+    for name in ("rolled", "plane_w"):
+        hdr = gen_cases.oceanset(o, N, name, swellphase=0.9)
+        out[f"vertices_600_{name}_40x30"] = o.gen(hdr, out["maps_600"], 40, 30)
+        out[f"oceanset_{name}"] = np.frombuffer(bytes(hdr), np.uint8).copy()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ocean_n64.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path))

@@ -43,6 +43,13 @@ def test_oracle_reproduces_golden(oracle, golden):
     assert bytes(steep) == golden["oceanset_steep"].tobytes()
     v = oracle.gen(steep, golden["maps_600"], 48, 40)
     assert np.allclose(v, golden["vertices_600_steep_48x40"], rtol=0, atol=1e-6)
+    for name in ("rolled", "plane_w"):
+        hdr = gen_cases.oceanset(oracle, N, name, swellphase=0.9)
+        assert bytes(hdr) == golden[f"oceanset_{name}"].tobytes()
+        v = oracle.gen(hdr, golden["maps_600"], 40, 30)
+        # positions reach 1e6 where the rays miss the plane: compare as the stated tolerance does
+        pos, tex, frame = gen_cases.compare(v, golden[f"vertices_600_{name}_40x30"])
+        assert pos < 1e-6 and tex < 1e-6 and frame < 1e-6
 
 
 def test_fused_update_equals_separate(oracle, golden):

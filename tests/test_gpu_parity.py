@@ -583,6 +583,29 @@ def test_gen_golden_steep_vertices(capi, oracle, torch):
     assert pos < 2e-4 and tex < 2e-4 and frame < 2e-4
 
 
+@pytest.mark.parametrize("name", ["rolled", "plane_w"])
+def test_gen_golden_cameras(capi, oracle, torch, name):
+    # committed fixtures: N = 64, 600 steps, a rolled camera / a sea level off z = 0 (tests/golden/make_golden.py)
+    import os
+
+    import gen_cases
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ocean_n64.npz"))
+    p = oracle.EXAMPLE
+    sx, sy = 40, 30
+    hs = capi.OceanSet.from_buffer_copy(g[f"oceanset_{name}"].tobytes())
+    verts = torch.zeros(sx * sy * 12, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    with capi.Ocean(64, 1) as oc:
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        oc.upload_state(0, g["h0"], g["phase_600"])
+        oc.displace()
+        oc.gen(0, hs, sx, sy, verts.data_ptr())
+        oc.sync()
+    pos, tex, frame = gen_cases.compare(verts.cpu().numpy().reshape(sy, sx, 12), g[f"vertices_600_{name}_40x30"])
+    assert pos < 2e-4 and tex < 2e-4 and frame < 2e-4
+
+
 # -- error behaviour -----------------------------------------------------------------------------------------
 
 
