@@ -234,3 +234,31 @@ def test_rendercomplete_on_the_host(capi, oracle):
             host = verts.to("cpu", non_blocking=False)
         assert torch.isfinite(host).all()
         oc.sync()
+
+
+def test_release_memory_with_maps_bound_inside_the_block(capi, helper, oracle):
+    # a VkBuffer commonly sits at an OFFSET inside its VkDeviceMemory: the maps are bound somewhere inside the imported
+    # block, then the block is released by its base pointer -- the handle must fall back to its own map buffer instead of
+    # writing through a pointer into unmapped memory
+    N = 64
+    p = oracle.EXAMPLE
+    _, h0 = oracle.seed(N, 1000, p["wavescale"], p["waveamplitude"], p["windspeed"], p["winddirection"])
+    nbytes = 2 * N * N * 16
+    offset = 4096
+    mem, fd = ExtMem(), ctypes.c_int(-1)
+    assert helper.extmem_create(nbytes + offset, ctypes.byref(mem), ctypes.byref(fd)) == 0
+    try:
+        with capi.Ocean(N, 1) as oc:
+            ptr = oc.import_memory_fd(fd.value, mem.bytes)
+            oc.set_cascade(0, p["wavescale"], p["choppiness"])
+            oc.upload_state(0, h0)
+            oc.bind_maps(ptr + offset, nbytes)
+            oc.update(DT)
+            oc.displace()
+            inside = oc.read_maps(0)
+            oc.release_memory(ptr)                       # the maps were bound at ptr + offset
+            oc.displace()                                # ... and now land in the handle's own buffer: no fault
+            oc.sync()
+            assert np.array_equal(oc.read_maps(0), inside)
+    finally:
+        assert helper.extmem_destroy(ctypes.byref(mem)) == 0
