@@ -20,8 +20,7 @@ D = ctypes.c_double
 SUPPORTED = (64, 128, 256, 512, 1024, 2048, 4096)
 MAX_CASCADES = 16
 
-OK, EINVAL, ESTATE, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
-ENOTREADY = 1
+OK, EINVAL, ESTATE, ENOMEM, EUNSUPPORTED, ENOTREADY = 0, -1, -2, -3, -4, -5
 PAYLOAD_MAPS, PAYLOAD_XYZ32, PAYLOAD_XYZ16 = 0, 1, 2
 
 

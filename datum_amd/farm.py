@@ -148,6 +148,11 @@ class TileGather:
         s = self.head
         if self.cuda and self.done[s] is not None:
             torch.cuda.current_stream(self.device).wait_event(self.done[s])   # WAR: the old collective still reads it
+        if self.cuda and self.consumed[s] is not None and not (self.collective or self.standin):
+            # world == 1, no collective: result() handed out payload[s] itself, so the consumer's release() must order the
+            # next PACK of the slot (with a collective it orders the next collective, in launch(): the consumer reads gathered[s])
+            torch.cuda.current_stream(self.device).wait_event(self.consumed[s])
+            self.consumed[s] = None
         elif self.work[s] is not None:
             self.work[s].wait()
             self.work[s] = None

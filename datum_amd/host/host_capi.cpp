@@ -102,7 +102,24 @@ extern "C"
   }
 
   void datum_host_params_set_deviceheight(void *p, int on) { static_cast<OceanParams*>(p)->deviceheight = (on != 0); }
-  void datum_host_params_set_hostphase(void *p, int on) { static_cast<OceanParams*>(p)->hostphase = (on != 0); }
+  // 0, or -1 when the history behind the host phase is gone (hostphase stays off: fetch_ocean_state first)
+  int datum_host_params_set_hostphase(void *p, int on)
+  {
+    OceanParams &o = *static_cast<OceanParams*>(p);
+
+    if (on && o.phaseupdates < o.firstupdate)
+    {
+      snprintf(g_error, sizeof(g_error), "hostphase: the update history behind OceanParams::phase is no longer recorded; fetch_ocean_state first");
+      return -1;
+    }
+
+    o.hostphase = (on != 0);
+
+    return 0;
+  }
+
+  // the field itself, as C++ code would set it (no validation: update_ocean then throws)
+  void datum_host_params_poke_hostphase(void *p, int on) { static_cast<OceanParams*>(p)->hostphase = (on != 0); }
 
   float *datum_host_params_seed(void *p) { return static_cast<OceanParams*>(p)->seed.data(); }
   float *datum_host_params_height(void *p) { return static_cast<OceanParams*>(p)->height.data(); }
@@ -126,7 +143,15 @@ extern "C"
     lerp_ocean_waves(*static_cast<OceanParams*>(p), wavescale, waveamplitude, windspeed, Vec2(dx, dy), t);
   }
 
-  void datum_host_update_ocean(void *p, float dt) { update_ocean(*static_cast<OceanParams*>(p), dt); }
+  int datum_host_update_ocean(void *p, float dt)
+  {
+    try
+    {
+      update_ocean(*static_cast<OceanParams*>(p), dt);
+      return 0;
+    }
+    catch(std::exception const &e) { return caught(e); }
+  }
 
   void datum_host_make_oceanset(datum_host_camera const *camera, void *p, datum_ocean_set *out)
   {
@@ -217,6 +242,13 @@ extern "C"
     }
     catch(std::exception const &e) { return caught(e); }
   }
+
+  size_t datum_host_release_parked_states(void *c, void *keep)
+  {
+    return release_parked_states(static_cast<HostContext*>(c)->context, static_cast<OceanParams const*>(keep));
+  }
+
+  int datum_host_parked_states(void *c) { return (int)static_cast<HostContext*>(c)->context.parked.size(); }
 
   int datum_host_fetch_ocean_state(void *c, void *p)
   {

@@ -165,8 +165,9 @@ namespace
     }
   }
 
-  // park the state that is resident on the context's device (h0 + phase, device to device) under its ids
-  void park_bound_state(OceanContext &context)
+  // park the state that is resident on the context's device (h0 + phase, device to device) under its ids.
+  // `keep`: a slot that must survive (the one about to be resumed): never the eviction victim
+  void park_bound_state(OceanContext &context, OceanContext::Parked const *keep = nullptr)
   {
     if (context.boundstate == 0)
       return;
@@ -181,19 +182,27 @@ namespace
 
     if (!slot && context.parked.size() < OceanContext::MaxParkedStates)
     {
-      context.parked.emplace_back();
+      void *device = nullptr;
+
+      // (allocated before the entry exists: a failed allocation leaves no half-made slot behind)
+      check(context.hip, datum_ocean_device_alloc(context.hip, bytes, &device), "datum_ocean_device_alloc");
+
+      context.parked.emplace_back();        // (may move the vector: `keep` is not looked at again on this path)
+      context.parked.back().device = device;
+
       slot = &context.parked.back();
-      check(context.hip, datum_ocean_device_alloc(context.hip, bytes, &slot->device), "datum_ocean_device_alloc");
     }
 
     if (!slot)
     {
-      slot = &context.parked[0];
-
-      for(auto &p : context.parked)      // least recently used
-        if (p.lastuse < slot->lastuse)
+      // least recently used, the slot about to be resumed excepted
+      for(auto &p : context.parked)
+        if (&p != keep && (!slot || p.lastuse < slot->lastuse))
           slot = &p;
     }
+
+    if (!slot)
+      return;      // (MaxParkedStates == 1 and that one is being resumed: the bound state goes back to its host copy + history)
 
     check(context.hip, datum_ocean_park_state(context.hip, 0, slot->device, bytes, &slot->flags), "datum_ocean_park_state");
 
@@ -220,14 +229,22 @@ namespace
 
     if (!continues(context.boundstate, context.appliedupdates, context.appliedlineage))
     {
+      // the slot to resume is looked up FIRST and kept out of the eviction: with more states than slots rendered round-robin the
+      // least recently used slot is exactly the state that comes next.  With the bound state parked into the slot being
+      // resumed they are swapped through the module's own buffers instead (park copies out after resume copied in would
+      // lose one of them), so: resume target found -> park the bound state elsewhere -> resume.
+      size_t resume = context.parked.size();
+
+      for(size_t i = 0; i < context.parked.size(); ++i)
+        if (continues(context.parked[i].stateid, context.parked[i].appliedupdates, context.parked[i].appliedlineage))
+          resume = i;
+
       if (context.boundstate != params.stateid)
-        park_bound_state(context);
+      {
+        park_bound_state(context, resume < context.parked.size() ? &context.parked[resume] : nullptr);
+      }
 
-      OceanContext::Parked *slot = nullptr;
-
-      for(auto &p : context.parked)
-        if (continues(p.stateid, p.appliedupdates, p.appliedlineage))
-          slot = &p;
+      OceanContext::Parked *slot = resume < context.parked.size() ? &context.parked[resume] : nullptr;
 
       if (slot)
       {
@@ -382,6 +399,31 @@ OceanContext::~OceanContext()
 }
 
 
+///////////////////////// release_parked_states /////////////////////////////
+size_t release_parked_states(OceanContext &context, OceanParams const *keep)
+{
+  size_t freed = 0;
+
+  for(size_t i = 0; i < context.parked.size(); )
+  {
+    if (keep && context.parked[i].stateid == keep->stateid)
+    {
+      ++i;
+      continue;
+    }
+
+    if (context.hip && context.parked[i].device)
+      datum_ocean_device_free(context.hip, context.parked[i].device);
+
+    freed += datum_ocean_state_bytes(context.resolution);
+
+    context.parked.erase(context.parked.begin() + i);
+  }
+
+  return freed;
+}
+
+
 ///////////////////////// seed_ocean ////////////////////////////////////////
 void seed_ocean(OceanParams &params)
 {
@@ -437,6 +479,11 @@ void lerp_ocean_waves(OceanParams &params, float wavescale, float waveamplitude,
 ///////////////////////// update_ocean ////////////////////////////////////
 void update_ocean(OceanParams &params, float dt)
 {
+  // hostphase switched on late: the steps between the host phase and the recorded history are gone (trimmed while it was
+  // off), so the host copy cannot be brought up to date from here -- fetch_ocean_state first.  Nothing is touched.
+  if (params.hostphase && params.phaseupdates < params.firstupdate)
+    throw runtime_error("ocean: OceanParams::hostphase was set after more than OceanParams::MaxRecordedUpdates update_ocean calls without it: the history behind OceanParams::phase is no longer recorded; fetch_ocean_state the params first, then set hostphase");
+
   params.swellphase = fmod(params.swellphase + (params.swellspeed * 2*pi<float>()/params.swelllength)*dt, 2*pi<float>());
 
   // phase[m][n] = fmod(phase[m][n] + dispersion(k)*dt, 2 pi) is done by the row-pass kernel, in history order, with the

@@ -157,6 +157,12 @@ struct OceanContext
     int flags = 0;
   };
 
+  // Capacity and footprint: up to MaxParkedStates parked copies of datum_ocean_state_bytes(resolution) = 12 N^2 bytes each
+  // (64^2: 48 KB; 1024^2: 12.6 MB; 4096^2: 201 MB, i.e. up to 805 MB of HBM per context), allocated on first use, reused least
+  // recently used first (the slot about to be resumed is never the victim) and held until release_parked_states() or the
+  // context's destruction -- a slot whose OceanParams was re-seeded or destroyed is not noticed by the context.  A context that
+  // alternates between MORE than MaxParkedStates + 1 states falls back to the host copy + recorded history for the evicted ones
+  // (OceanParams::hostphase, or a fetch_ocean_state at least every MaxRecordedUpdates / 2 steps, keeps that possible).
   static const std::size_t MaxParkedStates = 4;
 
   std::vector<Parked> parked;
@@ -274,6 +280,10 @@ void render_ocean_surface(OceanContext &context, Ocean const *target, Camera con
 
 // displacement maps only (ocean.sim .. ocean.map), no mesh: what the bench times
 void displace_ocean_surface(OceanContext &context, OceanParams const &params);
+
+// free the context's parked device copies (all of them, or all but `keep`'s): returns the bytes of HBM given back.  The states
+// themselves are not lost while their OceanParams can still be uploaded (host phase + recorded history)
+std::size_t release_parked_states(OceanContext &context, OceanParams const *keep = nullptr);
 
 // copy the device-resident phase (and, with deviceheight, h0) back into params (applies any queued update first)
 void fetch_ocean_state(OceanContext &context, OceanParams &params);

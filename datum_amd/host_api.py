@@ -65,14 +65,17 @@ def load():
             "datum_host_params_get": (None, [P, ctypes.POINTER(Scalars)]),
             "datum_host_params_set": (None, [P, ctypes.POINTER(Scalars)]),
             "datum_host_params_set_deviceheight": (None, [P, I]),
-            "datum_host_params_set_hostphase": (None, [P, I]),
+            "datum_host_params_set_hostphase": (I, [P, I]),
+            "datum_host_params_poke_hostphase": (None, [P, I]),
+            "datum_host_release_parked_states": (ctypes.c_size_t, [P, P]),
+            "datum_host_parked_states": (I, [P]),
             "datum_host_params_seed": (ctypes.POINTER(F), [P]),
             "datum_host_params_height": (ctypes.POINTER(F), [P]),
             "datum_host_params_phase": (ctypes.POINTER(F), [P]),
             "datum_host_seed_ocean": (None, [P, U32, I]),
             "datum_host_lerp_ocean_swell": (None, [P, F, F, F, F, F, F]),
             "datum_host_lerp_ocean_waves": (None, [P, F, F, F, F, F, F]),
-            "datum_host_update_ocean": (None, [P, F]),
+            "datum_host_update_ocean": (I, [P, F]),
             "datum_host_make_oceanset": (None, [ctypes.POINTER(CameraDesc), P, ctypes.POINTER(capi.OceanSet)]),
             "datum_host_twiddle_table": (I, [I, P]),
             "datum_host_context_create": (P, [I, I]),
@@ -155,7 +158,12 @@ class OceanParams:
 
     def set_hostphase(self, on=True):
         """Extension: update_ocean also advances the host copy of the phase, as the reference does (ocean.cpp:223-233)."""
-        self.lib.datum_host_params_set_hostphase(self.p, 1 if on else 0)
+        if self.lib.datum_host_params_set_hostphase(self.p, 1 if on else 0) != 0:
+            raise HostError(self.lib.datum_host_last_error().decode())
+
+    def poke_hostphase(self, on=True):
+        """OceanParams::hostphase = on, as C++ code sets the public field (no validation; tests)."""
+        self.lib.datum_host_params_poke_hostphase(self.p, 1 if on else 0)
 
     def seed_ocean(self, rngseed=None):
         self.lib.datum_host_seed_ocean(self.p, 0 if rngseed is None else rngseed, 1 if rngseed is None else 0)
@@ -167,7 +175,8 @@ class OceanParams:
         self.lib.datum_host_lerp_ocean_waves(self.p, wavescale, waveamplitude, windspeed, winddirection[0], winddirection[1], t)
 
     def update_ocean(self, dt):
-        self.lib.datum_host_update_ocean(self.p, dt)
+        if self.lib.datum_host_update_ocean(self.p, dt) != 0:
+            raise HostError(self.lib.datum_host_last_error().decode())
 
     def oceanset(self, camera=None):
         out = capi.OceanSet()
@@ -240,6 +249,13 @@ class OceanContext:
 
     def displace_ocean_surface(self, params):
         self._check(self.lib.datum_host_displace_ocean_surface(self.c, params.p))
+
+    def release_parked_states(self, keep=None):
+        """Free the context's parked device copies (all but `keep`'s); returns the bytes given back."""
+        return self.lib.datum_host_release_parked_states(self.c, keep.p if keep is not None else None)
+
+    def parked_states(self):
+        return self.lib.datum_host_parked_states(self.c)
 
     def fetch_ocean_state(self, params):
         self._check(self.lib.datum_host_fetch_ocean_state(self.c, params.p))

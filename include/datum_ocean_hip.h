@@ -8,8 +8,9 @@
  * per-frame OceanSet upload (":729-749").  Plain pointers and sizes only; no C++ or torch types.
  *
  * Conventions
- *   - every function returns 0 on success; a negative DATUM_OCEAN_E* code for misuse; a positive
- *     value is a hipError_t.  Nothing throws.  datum_ocean_last_error() gives the text.
+ *   - every function returns 0 on success; a negative DATUM_OCEAN_E* code of this module (misuse, or ENOTREADY from the
+ *     two polling calls); a positive value is a hipError_t (an ncclResult_t never leaves the module: the farm entry points
+ *     map it to DATUM_OCEAN_ECOMM).  Nothing throws.  datum_ocean_last_error() gives the text.
  *     (reference: throw std::runtime_error on device failure, ocean.cpp:271 / vulkan.cpp:550;
  *     the C++ shim in datum_amd/host re-throws.)
  *   - one HIP stream per handle; calls enqueue and return; datum_ocean_sync() is the fence wait of
@@ -37,8 +38,11 @@ enum
   DATUM_OCEAN_EINVAL = -1,    /* bad argument (null pointer, unsupported resolution, cascade out of range) */
   DATUM_OCEAN_ESTATE = -2,    /* call order misuse (e.g. displace before upload_state)                     */
   DATUM_OCEAN_ENOMEM = -3,
-  DATUM_OCEAN_EUNSUPPORTED = -4   /* the HIP runtime on this machine lacks the feature (external semaphores on ROCm 7.0.x: use the
+  DATUM_OCEAN_EUNSUPPORTED = -4,  /* the HIP runtime on this machine lacks the feature (external semaphores on ROCm 7.0.x: use the
                                    host bridge, datum_ocean_on_complete / datum_ocean_query)                                  */
+  DATUM_OCEAN_ENOTREADY = -5      /* datum_ocean_query / datum_ocean_farm_query only: the work is still running (not a failure).
+                                   A module code, because every positive return value is a hipError_t (hipErrorInvalidValue
+                                   is 1) and a poller must be able to tell "not yet" from "the query itself failed"         */
 };
 
 typedef struct datum_ocean_ctx *datum_ocean_t;
@@ -181,7 +185,6 @@ int datum_ocean_signal(datum_ocean_t ctx, void **hip_event);
  *   query        DATUM_OCEAN_OK when everything enqueued before the last datum_ocean_signal has finished,
  *                DATUM_OCEAN_ENOTREADY while it has not; never blocks (a renderer that polls once per frame).
  * INTEGRATION.md 3a has the call sequence. */
-#define DATUM_OCEAN_ENOTREADY 1
 int datum_ocean_on_complete(datum_ocean_t ctx, void (*callback)(void *user), void *user);
 int datum_ocean_query(datum_ocean_t ctx);
 

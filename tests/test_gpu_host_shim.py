@@ -246,6 +246,60 @@ def test_two_oceans_on_one_context_for_longer_than_the_history(oracle):
         assert np.sqrt(((got.astype(np.float64) - want) ** 2).mean()) < 1e-5
 
 
+def test_six_oceans_round_robin_on_one_context(oracle):
+    # round-3 advisor finding: a context parks up to MaxParkedStates (4) states besides the one that is bound.  With more
+    # states than that rendered round-robin, the least recently used slot is exactly the state that comes next: parking
+    # before looking the resume slot up evicted it, every switch fell back to a host upload + a replay of the whole history,
+    # and past the trimmed history it threw.  Now the resume slot is found first and kept out of the eviction.  Six states
+    # (one bound + four parked + one that always has to come from the host) for longer than the history records: the five
+    # that fit keep their device copies (after the sixth intruded, one lap of host uploads + replays, then slots again -- a
+    # state evicted AFTER its history was trimmed could not come back without hostphase, as ocean.h documents); the phase of
+    # every one is bit-exact; release_parked_states gives the memory back.
+    import numpy as np
+
+    from datum_amd import host_api
+
+    N = 64
+    dt = np.float32(1 / 60)
+    K = 6
+    ws = [22.0 + 7.0 * k for k in range(K)]
+    ps = []
+    for k in range(K):
+        p = host_api.OceanParams(N, **dict(host_api.EXAMPLE_TUNABLES, wavescale=ws[k]))
+        p.seed_ocean(1000 + k)
+        p.set_hostphase(k == K - 1)        # the one state without a slot lives on its host copy, as the reference's all do
+        ps.append(p)
+    phases = [np.zeros((N, N), np.float32) for _ in range(K)]
+    steps = 4400                          # more update_ocean calls per state than OceanParams::MaxRecordedUpdates records
+    with host_api.OceanContext(N, device=0) as ctx:
+        for frame in range(steps):
+            for k in range(5):
+                ps[k].update_ocean(dt)
+                ctx.displace_ocean_surface(ps[k])
+            if frame in (0, 600):         # the sixth state intrudes while the others' histories still reach their host copies
+                ps[5].update_ocean(dt)
+                oracle.update(phases[5], ws[5], dt)
+                ctx.displace_ocean_surface(ps[5])
+        assert ctx.parked_states() == 4
+        for k in range(5):
+            for _ in range(steps):
+                oracle.update(phases[k], ws[k], dt)
+        for k in range(K):
+            ctx.fetch_ocean_state(ps[k])
+            assert np.array_equal(ps[k].phase, phases[k]), k
+        freed = ctx.release_parked_states(keep=ps[0])
+        assert freed > 0 and freed % (12 * N * N) == 0
+        assert ctx.parked_states() <= 1
+        ctx.release_parked_states()
+        assert ctx.parked_states() == 0
+        # and the states are still renderable (host copy as of the fetch + recorded history)
+        ps[2].update_ocean(dt)
+        oracle.update(phases[2], ws[2], dt)
+        ctx.displace_ocean_surface(ps[2])
+        ctx.fetch_ocean_state(ps[2])
+        assert np.array_equal(ps[2].phase, phases[2])
+
+
 def test_diverged_copies_share_an_id_but_not_a_history(oracle):
     # copy P to Q, then advance them differently: the reference's PODs diverge freely.  Both carry the same state id and
     # history numbers; the context must notice (lineage of the last applied entry) and render each with its own phase.

@@ -893,10 +893,13 @@ def test_tile_gather_on_device(capi, oracle, torch):
         dist.destroy_process_group()
 
 
-def test_tile_gather_consumer_on_another_stream(capi, oracle, torch):
+@pytest.mark.parametrize("standin", [1, 0])
+def test_tile_gather_consumer_on_another_stream(capi, oracle, torch, standin):
     # TileGather.release(): a consumer that reads the gathered buffer on ITS OWN stream (a renderer's upload, a reduction)
     # must finish before the slot's next collective overwrites the buffer.  The consumer here is slow on purpose (many passes
     # over the buffer); the stand-in for the collective is the paced copy kernel of bench.py --standin-peers (one GPU).
+    # standin = 0: world == 1 and no collective at all -- result() hands out the payload buffer itself, and release() has
+    # to order the slot's next PACK (round-3 advisor finding: acquire() did not wait for it).
     from datum_amd import farm
 
     N, C, fmt = 256, 2, "xyz32"
@@ -908,9 +911,10 @@ def test_tile_gather_consumer_on_another_stream(capi, oracle, torch):
         for c in range(C):
             oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c], p["choppiness"])
             oc.upload_state(c, make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c]))
-        tg = farm.TileGather(farm.payload_numel(N, C, fmt), dtype, "cuda:0", 1, standin_peers=1, standin_workgroups=8, standin_gbps=0.0)
+        tg = farm.TileGather(farm.payload_numel(N, C, fmt), dtype, "cuda:0", 1, standin_peers=standin, standin_workgroups=8, standin_gbps=0.0)
         nbytes = oc.payload_bytes(code)
         n = farm.payload_numel(N, C, fmt)
+        first = n if standin else 0            # where this rank's (the stand-in's first copy of the) payload lies in `out`
         sums, wants = [], []
         for b in range(6):
             oc.update(DT)
@@ -925,7 +929,7 @@ def test_tile_gather_consumer_on_another_stream(capi, oracle, torch):
                 consumer.wait_event(ready)
                 acc = torch.zeros((), dtype=torch.float64, device="cuda:0")
                 for _ in range(40):
-                    acc = acc + out[n:2 * n].double().abs().sum()
+                    acc = acc + out[first:first + n].double().abs().sum()
                 sums.append(acc)
                 tg.release()                                    # the slot's next collective waits for this point
             wants.append(sum(float(np.abs(oc.read_maps(c)[0, ..., :3].astype(np.float64)).sum()) for c in range(C)) * 40)

@@ -156,3 +156,38 @@ def test_hostphase_is_the_reference_loop(host, oracle):
     assert np.array_equal(p.phase, phase)
     assert np.all(q.phase == 0)
     assert p.scalars().pending <= 4096 and q.scalars().pending <= 4096
+
+
+def test_hostphase_switched_on_after_the_history_was_trimmed(host):
+    # round-3 advisor finding: hostphase is a public bool; switched on after more than MaxRecordedUpdates steps without it
+    # (and without a fetch) the steps between the host phase and the recorded history are gone.  update_ocean used to index
+    # updates[phaseupdates - firstupdate] with phaseupdates < firstupdate (an unsigned underflow: out of bounds).  Now the
+    # setter refuses, and the bare field -- as C++ code would set it -- makes update_ocean throw and leave the params as it was.
+    p = host.OceanParams(32, **host.EXAMPLE_TUNABLES)
+    p.seed_ocean(1000)
+    dt = np.float32(1 / 60)
+    for _ in range(4300):
+        p.update_ocean(dt)
+    pending = p.scalars().pending
+    assert pending < 4300                         # the history was trimmed
+    with pytest.raises(host.HostError, match="fetch_ocean_state"):
+        p.set_hostphase(True)
+    p.poke_hostphase(True)
+    sp = p.scalars().swellphase
+    with pytest.raises(host.HostError, match="hostphase was set after"):
+        p.update_ocean(dt)
+    assert p.scalars().pending == pending         # the refused step is not recorded, nothing was advanced
+    assert p.scalars().swellphase == sp
+    assert np.all(p.phase == 0)
+    p.poke_hostphase(False)
+    p.update_ocean(dt)                            # and the params goes on as before
+    assert p.scalars().pending == pending + 1
+    assert p.scalars().swellphase != sp
+    # switched on in time (history intact) it catches up in one call
+    q = host.OceanParams(32, **host.EXAMPLE_TUNABLES)
+    q.seed_ocean(1000)
+    for _ in range(100):
+        q.update_ocean(dt)
+    q.set_hostphase(True)
+    q.update_ocean(dt)
+    assert np.any(q.phase != 0)
