@@ -5,7 +5,7 @@ HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-f
 
 LIB = datum_amd/lib/libdatum_ocean_hip.so
 SRC = datum_amd/csrc/ocean_capi.hip
-DEPS = datum_amd/csrc/ocean_kernels.hip datum_amd/csrc/ocean_gen.hip datum_amd/csrc/ocean_fft_core.h include/datum_ocean_hip.h
+DEPS = datum_amd/csrc/ocean_kernels.hip datum_amd/csrc/ocean_gen.hip datum_amd/csrc/ocean_farm.hip datum_amd/csrc/ocean_fft_core.h include/datum_ocean_hip.h
 
 HOSTLIB = datum_amd/lib/libdatum_ocean_host.so
 HOSTSRC = datum_amd/host/ocean.cpp datum_amd/host/host_capi.cpp
@@ -35,7 +35,12 @@ oracle:
 
 # datum's example-ocean flow against the host shim, headless
 EXAMPLE = examples/ocean_headless
-examples: $(EXAMPLE)
+FARMEXAMPLE = examples/ocean_farm
+examples: $(EXAMPLE) $(FARMEXAMPLE)
+
+# the tile farm from C++ alone (N processes, RCCL through the C ABI)
+$(FARMEXAMPLE): examples/ocean_farm.cpp $(HOSTLIB)
+	$(CXX) -O2 -std=c++14 -Wall -o $@ examples/ocean_farm.cpp -Ldatum_amd/lib -ldatum_ocean_host -ldatum_ocean_hip -Wl,-rpath,'$$ORIGIN/../datum_amd/lib'
 
 $(EXAMPLE): examples/ocean_headless.cpp $(HOSTLIB)
 	$(CXX) -O2 -std=c++14 -Wall -o $@ examples/ocean_headless.cpp -Ldatum_amd/lib -ldatum_ocean_host -ldatum_ocean_hip -Wl,-rpath,'$$ORIGIN/../datum_amd/lib'
@@ -58,7 +63,7 @@ resource-usage: $(SRC) $(DEPS)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(SRC) 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" 
 
 clean:
-	rm -f $(LIB) $(HOSTLIB) $(STANDIN) $(EMUL) $(EXAMPLE) $(EXTMEM)
+	rm -f $(LIB) $(HOSTLIB) $(STANDIN) $(EMUL) $(EXAMPLE) $(FARMEXAMPLE) $(EXTMEM)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle emul helpers examples clean resource-usage

@@ -70,6 +70,13 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
     ap.add_argument("--no-frame", action="store_true", help="skip the 64 x 64 reference-frame timing")
     ap.add_argument("--no-check", action="store_true", help="skip the output sanity check (timing-only ablation builds)")
+    ap.add_argument("--no-regime", action="store_true",
+                    help="skip the beyond-Infinity-Cache leg (10 steps of 1024x1024 x 16 after the timed region: roofline.hbm_regime)")
+    ap.add_argument("--python-gather", action="store_true",
+                    help="N > 1: issue the all-gather from Python (datum_amd/farm.py over torch.distributed) instead of the module's own "
+                         "RCCL communicator (datum_ocean_farm_*); for comparison only")
+    ap.add_argument("--cpu-baseline-child", nargs=3, metavar=("N", "CASCADES", "SECONDS"), default=None,
+                    help="internal: the cpu_baseline leg, run as a child process with pinned OpenMP threads; prints one JSON object")
     return ap.parse_args()
 
 
@@ -136,30 +143,63 @@ def lavapipe_probe(N):
         return {"status": f"toolchain present but the harness failed: {e}", "probe": found}
 
 
-def cpu_baseline(N, cascades, states, budget):
-    """The oracle (oracle/ocean_oracle.cpp, OpenMP over rows / columns) timed on this host on a bounded sample of
-    the same workload.  A reported baseline, not a target.  kind = "port": the reference itself cannot be built or
-    run here (no Vulkan / lavapipe / glslang / leap: DESIGN.md)."""
+def cpu_baseline_child(N, cascades, budget):
+    """Runs in a CHILD process of bench.py (never touches the GPU, imports neither torch nor datum_amd): the oracle
+    (oracle/ocean_oracle.cpp, OpenMP over rows / columns) on the same workload -- seeds mt19937(1000 + cascade), wave scales
+    22 / 64 / 176 / 512, example-ocean parameters -- with its threads pinned (the parent sets OMP_PROC_BIND=close,
+    OMP_PLACES=cores before this process starts: an unpinned run moved between 14 and 27 grids/s from box to box).
+    Three timed runs inside the budget; the best is the baseline."""
     from oracle import oracle
 
+    scales = (22.0, 64.0, 176.0, 512.0)
     w = oracle.weights(N)
     scratch = np.empty(6 * N * N, np.float32)
     out = np.empty((2, N, N, 4), np.float32)
+    states = [(oracle.seed(N, 1000 + c, wavescale=scales[c % 4])[1], scales[c % 4]) for c in range(cascades)]
     phases = [np.zeros((N, N), np.float32) for _ in range(cascades)]
     # untimed touch
     oracle.displace(states[0][0], phases[0], states[0][1], 1.35, dt=DT, w=w, mt=True, scratch=scratch, out=out)
-    grids = 0
-    t0 = time.perf_counter()
-    while True:
-        for c in range(cascades):
-            oracle.displace(states[c][0], phases[c], states[c][1], 1.35, dt=DT, w=w, mt=True, scratch=scratch, out=out)
-            grids += 1
-        el = time.perf_counter() - t0
-        if el >= budget or grids >= 64 * cascades:
-            break
-    return dict(value=grids / el, unit="grids/s", cores=oracle.num_threads(), kind="port", lavapipe=lavapipe_probe(N),
-                sample=f"{grids} grids = {grids // cascades} steps of {N}x{N} x {cascades} cascades in {el:.1f} s, "
-                       f"oracle/ocean_oracle.cpp with OpenMP over rows/columns")
+    runs = []
+    for _ in range(3):
+        grids = 0
+        t0 = time.perf_counter()
+        while True:
+            for c in range(cascades):
+                oracle.displace(states[c][0], phases[c], states[c][1], 1.35, dt=DT, w=w, mt=True, scratch=scratch, out=out)
+                grids += 1
+            el = time.perf_counter() - t0
+            if el >= budget / 3.0 or grids >= 32 * cascades:
+                break
+        runs.append((grids / el, grids, el))
+    best = max(runs)
+    print(json.dumps({"value": best[0], "grids": best[1], "seconds": best[2], "runs_grids_per_s": [r[0] for r in runs],
+                      "omp_max_threads": oracle.num_threads(), "cpu_count": os.cpu_count(),
+                      "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                      "omp_proc_bind": os.environ.get("OMP_PROC_BIND"), "omp_places": os.environ.get("OMP_PLACES")}), flush=True)
+    return 0
+
+
+def cpu_baseline(N, cascades, budget):
+    """The oracle timed on this host on a bounded sample of the same workload, in a child process (started with subprocess,
+    no exec in this GPU-initialised process) so that its OpenMP runtime starts with pinned threads whatever this process has
+    loaded.  A reported baseline, not a target.  kind = "port": the reference itself cannot be built or run here (no
+    Vulkan / lavapipe / glslang / leap: DESIGN.md)."""
+    import subprocess
+
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
+    env.pop("OMP_NUM_THREADS", None)
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(N), str(cascades), str(budget)],
+                             env=env, capture_output=True, text=True, timeout=max(120.0, 10.0 * budget))
+        j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as e:  # noqa: BLE001
+        return dict(value=None, unit="grids/s", cores=None, kind="port", lavapipe=lavapipe_probe(N), sample=f"the child process failed: {e}")
+    return dict(value=j["value"], unit="grids/s", cores=j["omp_max_threads"], kind="port", lavapipe=lavapipe_probe(N),
+                host={"omp_get_max_threads": j["omp_max_threads"], "os.cpu_count": j["cpu_count"], "sched_getaffinity": j["affinity"],
+                      "OMP_PROC_BIND": j["omp_proc_bind"], "OMP_PLACES": j["omp_places"]},
+                runs_grids_per_s=j["runs_grids_per_s"],
+                sample=f"best of three runs: {j['grids']} grids = {j['grids'] // cascades} steps of {N}x{N} x {cascades} cascades in {j['seconds']:.1f} s, "
+                       f"oracle/ocean_oracle.cpp with OpenMP over rows/columns, {j['omp_max_threads']} pinned threads (child process)")
 
 
 def launch_ranks(args):
@@ -254,6 +294,9 @@ def baseline_config(N, C, world, spectrum):
 def main():
     args = parse()
 
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(int(args.cpu_baseline_child[0]), int(args.cpu_baseline_child[1]), float(args.cpu_baseline_child[2]))
+
     # N ranks without a launcher: this process only starts them (nothing below runs here)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
@@ -294,15 +337,12 @@ def main():
     # state: this rank's cascades, seeded on the host exactly as seed_ocean does (mt19937(1000 + global index))
     oc = capi.Ocean(N, C, device=local_rank)
     oc.set_spectrum_format(args.spectrum == "fp16")
-    states = []
     for c, g in enumerate(farm.owned_grids(rank, world, C)):
         ws = farm.grid_wavescale(g, C)
         p = host_api.OceanParams(N, **dict(host_api.EXAMPLE_TUNABLES, wavescale=ws))
         p.seed_ocean(farm.grid_seed(g))
         oc.set_cascade(c, ws, 1.35)
         oc.upload_state(c, p.height)
-        if rank == 0 and world == 1:
-            states.append((p.height.copy(), ws))
         if c == 0:
             genset = p.oceanset()          # the OceanSet header of render_ocean_surface for the example camera
         del p
@@ -313,13 +353,23 @@ def main():
     stream = torch.cuda.Stream(dev)   # a real (non-default) stream: events and RCCL below are ordered on it too
     torch.cuda.set_stream(stream)
     oc.set_stream(stream.cuda_stream)
-    # the all-gather of north_star (datum_amd/farm.py): payload packed by the module, double-buffered, collective on a second stream
+    # the all-gather of north_star.  N > 1 (or --force-collective): the module's own farm (datum_ocean_farm_*: RCCL communicator,
+    # communication stream, double-buffered payload and event choreography inside the C ABI); torch.distributed only started the
+    # ranks' rendezvous and carries the 128-byte id to them.  --standin-peers (one GPU, measurement aid) and --python-gather keep
+    # the Python choreography of datum_amd/farm.py.
     gathering = (multi and args.gather != "none") or args.standin_peers > 0
+    native = gathering and multi and not args.python_gather
     tg = None
     if gathering:
         code, pdtype, _ = farm.PAYLOADS[args.payload]
         pbytes = oc.payload_bytes(code)
         assert pbytes == farm.payload_bytes(N, C, args.payload)
+    if native:
+        box = [capi.farm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        oc.farm_init(box[0], rank, world, code, slots=2)
+        farm_info = oc.farm_info()
+    elif gathering:
         tg = farm.TileGather(farm.payload_numel(N, C, args.payload), pdtype, dev, world, standin_peers=args.standin_peers,
                              force_collective=args.force_collective, standin_workgroups=args.standin_workgroups, standin_gbps=args.standin_gbps)
 
@@ -327,20 +377,26 @@ def main():
         oc.update(DT)
         oc.displace()
 
-    def pack():
+    def gather():
+        """pack (compute stream, behind the last displace) + all-gather (communication stream); returns the slot, does not block"""
+        if native:
+            return oc.farm_gather()
         buf = tg.acquire()
         oc.pack_displacement(code, buf.data_ptr(), pbytes)
+        return tg.launch()
+
+    def await_gather(slot):
+        """the compute stream waits for the slot's collective (a consumer on that stream would read the field now)"""
+        if native:
+            oc.farm_result(slot)
+        else:
+            tg.result()
 
     for _ in range(args.warmup):
         step()
     if gathering:
-        # one untimed round of the whole choreography (RCCL sets its channels up on first use), then the payload of the
-        # warm-up batch, ready to be gathered under the timed batch
-        pack()
-        tg.launch()
-        tg.result()
-        if args.gather == "pipelined" and args.gather_every == 0:
-            pack()
+        # one untimed round of the whole choreography (RCCL sets its channels up on first use)
+        await_gather(gather())
 
     torch.cuda.synchronize(dev)
     if multi:
@@ -356,10 +412,10 @@ def main():
     oc.profile_begin((args.steps + stride - 1) // stride, stride)
     ev0, ev1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
 
-    # The timed region holds exactly --steps steps, one pack and one all-gather.  pipelined: the gather is the PREVIOUS
-    # batch's (its payload was packed above), issued first and running on the communication stream while this batch's kernels
-    # run; this batch's payload is packed at the end and would be gathered under the next batch.  serial: this batch's own
-    # payload is packed and gathered after its last step.
+    # The timed region holds exactly --steps steps, one pack and one all-gather.  pipelined: the field as it stands when the
+    # batch begins (the previous batch's result) is packed and its all-gather runs on the communication stream while this
+    # batch's kernels run on the compute stream.  serial: this batch's own field is packed and gathered after its last step and
+    # the compute stream waits for it.
     # --gather-every K: a pack and a gather after every K steps instead (K = 1: the field is reassembled every step).
     every = args.gather_every if gathering else 0
     gathers = 0
@@ -370,28 +426,24 @@ def main():
         for i in range(args.steps):
             step()
             if (i + 1) % every == 0:
-                pack()
-                slot = tg.launch()
+                slot = gather()
                 gathers += 1
                 if args.gather == "serial":
-                    tg.result()
+                    await_gather(slot)
         if slot is None:
-            pack()
-            slot = tg.launch()
+            slot = gather()
             gathers += 1
     elif gathering and args.gather == "pipelined":
-        slot = tg.launch()
+        slot = gather()
         gathers = 1
         for _ in range(args.steps):
             step()
-        pack()
     elif gathering:
         for _ in range(args.steps):
             step()
-        pack()
-        slot = tg.launch()
+        slot = gather()
         gathers = 1
-        tg.result()
+        await_gather(slot)
     else:
         for _ in range(args.steps):
             step()
@@ -403,6 +455,42 @@ def main():
     elapsed = time.perf_counter() - t0
 
     row_ms, col_ms, nprof = oc.profile_end()
+
+    # Beyond the Infinity Cache (outside the timed region): the headline's working set, 1024^2 x 4 = 252 MB, fits the 256 MiB
+    # Infinity Cache and its kernels run above what HBM alone delivers; the same kernels over 16 cascades (1 GB) cannot.  Ten
+    # steps after five, every step's two kernels timed with dispatch events, fractions on ALGORITHMIC bytes like `roofline`.
+    regime = None
+    if rank == 0 and world == 1 and not args.no_regime and (N, C, args.spectrum) == (1024, 4, "fp32"):
+        RC = 16
+        with capi.Ocean(N, RC, device=local_rank) as big:
+            big.set_stream(stream.cuda_stream)
+            for c in range(RC):
+                ws = farm.CASCADE_WAVESCALES[c % 4]
+                p = host_api.OceanParams(N, **dict(host_api.EXAMPLE_TUNABLES, wavescale=ws))
+                p.seed_ocean(farm.grid_seed(c))
+                big.set_cascade(c, ws, 1.35)
+                big.upload_state(c, p.height)
+                del p
+            for _ in range(5):
+                big.update(DT)
+                big.displace()
+            r0, r1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+            big.profile_begin(10, 1)
+            r0.record(stream)
+            for _ in range(10):
+                big.update(DT)
+                big.displace()
+            r1.record(stream)
+            torch.cuda.synchronize(dev)
+            brow_ms, bcol_ms, bn = big.profile_end()
+            brow_b, bcol_b = big.algorithmic_bytes()
+            big.set_stream(None)
+        regime = {"workload": f"{N}x{N} x {RC} cascades fp32 (1 GB working set: beyond the 256 MiB Infinity Cache), 10 steps after 5, outside the timed region",
+                  "step_frac": (brow_b + bcol_b) / ((brow_ms + bcol_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "col_frac": bcol_b / (bcol_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "row_frac": brow_b / (brow_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "rowpass_ms": brow_ms, "colpass_ms": bcol_ms, "launches_timed": bn,
+                  "grids_per_s": 10 * RC / (r0.elapsed_time(r1) * 1e-3),
+                  "frac_on_bytes_moved": (80.0 * N * N * RC) / ((brow_ms + bcol_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     # ocean.gen (reported separately, as vertices/s): the 1024 x 1024 projected-grid mesh of the example
     # (examples/ocean/ocean.cpp:59) from cascade 0's maps, outside the timed region above
@@ -458,7 +546,7 @@ def main():
             o64.set_stream(None)
         del p64
     compute_ms = ev0.elapsed_time(ev1)     # the compute stream's share (serial: includes the gather it waits for)
-    gather_ms = tg.last_collective_ms(slot) if gathering else 0.0
+    gather_ms = (oc.farm_wait(slot) if native else tg.last_collective_ms(slot)) if gathering else 0.0
 
     if multi:
         t = torch.tensor([elapsed, compute_ms, gather_ms], dtype=torch.float64, device=dev)
@@ -514,7 +602,8 @@ def main():
                            + (f", every {every} step(s)" if every > 0 else f", once per {args.steps} steps") + ")" if args.standin_peers else "n/a (1 GPU)")),
                 "gathers_in_timed_region": gathers,
                 "collective_world_size": (dist.get_world_size() if multi else None),
-                "collective_backend": ("nccl (RCCL)" if multi else None),
+                "collective_backend": (None if not multi else (f"RCCL {farm_info['rccl_version']} through the module's C ABI (datum_ocean_farm_*), {farm_info['slots']} slots" if native
+                                                               else "RCCL through torch.distributed (datum_amd/farm.py)")),
                 "measured_on_hardware": ("this line" if world > 1 else "1 GPU"),
                 "payload": args.payload if gathering else None,
                 "payload_bytes_per_rank": pbytes if gathering else None,
@@ -540,6 +629,7 @@ def main():
                 "step_GBps": step_ach,
                 "step_frac": step_ach / HBM_PEAK_GBS,
                 "launches_timed": nprof,
+                "hbm_regime": regime,
             },
             "compute_ms": compute_ms,
             "gather_ms": gather_ms,
@@ -549,7 +639,7 @@ def main():
         }
 
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(N, C, states, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(N, C, args.cpu_seconds)
         else:
             line["cpu_baseline"] = None
 

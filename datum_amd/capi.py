@@ -20,7 +20,8 @@ D = ctypes.c_double
 SUPPORTED = (64, 128, 256, 512, 1024, 2048, 4096)
 MAX_CASCADES = 16
 
-OK, EINVAL, ESTATE, ENOMEM, EUNSUPPORTED, ENOTREADY = 0, -1, -2, -3, -4, -5
+OK, EINVAL, ESTATE, ENOMEM, EUNSUPPORTED, ENOTREADY, ECOMM = 0, -1, -2, -3, -4, -5, -6
+FARM_ID_BYTES = 128
 PAYLOAD_MAPS, PAYLOAD_XYZ32, PAYLOAD_XYZ16 = 0, 1, 2
 
 
@@ -70,6 +71,15 @@ SYMBOLS = {
     "datum_ocean_gen": (I, [P, I, ctypes.POINTER(OceanSet), I, I, P]),
     "datum_ocean_payload_bytes": (I, [P, I, ctypes.POINTER(ctypes.c_size_t)]),
     "datum_ocean_pack_displacement": (I, [P, I, P, ctypes.c_size_t]),
+    "datum_ocean_farm_unique_id": (I, [P, ctypes.c_size_t]),
+    "datum_ocean_farm_init": (I, [P, P, ctypes.c_size_t, I, I, I, I]),
+    "datum_ocean_farm_shutdown": (I, [P]),
+    "datum_ocean_farm_info": (I, [P, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(I), ctypes.POINTER(I)]),
+    "datum_ocean_farm_gather": (I, [P, ctypes.POINTER(I)]),
+    "datum_ocean_farm_result": (I, [P, I, P, I, ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]),
+    "datum_ocean_farm_release": (I, [P, I, P, I]),
+    "datum_ocean_farm_query": (I, [P, I]),
+    "datum_ocean_farm_wait": (I, [P, I, ctypes.POINTER(F)]),
     "datum_ocean_read_maps": (I, [P, I, P]),
     "datum_ocean_sync": (I, [P]),
     "datum_ocean_wait_event": (I, [P, P]),
@@ -233,6 +243,51 @@ class Ocean:
         """Enqueue the packing of every cascade's displacement into caller-owned device memory (all-gather payload)."""
         self._check(self.lib.datum_ocean_pack_displacement(self.h, fmt, P(device_ptr), nbytes))
 
+    # -- the tile farm (include/datum_ocean_hip.h: datum_ocean_farm_*): the RCCL all-gather lives in the module --------
+
+    def farm_init(self, unique_id, rank, world, fmt, slots=2):
+        """Join the farm's communicator (collective over the ranks).  unique_id: the 128 bytes of farm_unique_id() on rank 0."""
+        assert len(unique_id) == FARM_ID_BYTES
+        buf = (ctypes.c_char * FARM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._check(self.lib.datum_ocean_farm_init(self.h, buf, FARM_ID_BYTES, rank, world, fmt, slots))
+
+    def farm_shutdown(self):
+        self._check(self.lib.datum_ocean_farm_shutdown(self.h))
+
+    def farm_info(self):
+        rank, world, fmt, slots, ver = I(), I(), I(), I(), I()
+        nbytes = ctypes.c_size_t()
+        self._check(self.lib.datum_ocean_farm_info(self.h, ctypes.byref(rank), ctypes.byref(world), ctypes.byref(fmt), ctypes.byref(nbytes), ctypes.byref(slots), ctypes.byref(ver)))
+        return dict(rank=rank.value, world=world.value, format=fmt.value, payload_bytes=nbytes.value, slots=slots.value, rccl_version=ver.value)
+
+    def farm_gather(self):
+        """Enqueue pack + all-gather of the displacement field as of the last displace; returns the slot.  Does not block."""
+        slot = I()
+        self._check(self.lib.datum_ocean_farm_gather(self.h, ctypes.byref(slot)))
+        return slot.value
+
+    def farm_result(self, slot, stream_ptr=None):
+        """(device pointer, bytes) of the slot's gathered block; `stream_ptr` (None: the handle's stream) waits for the collective."""
+        p, n = P(), ctypes.c_size_t()
+        self._check(self.lib.datum_ocean_farm_result(self.h, slot, P(stream_ptr) if stream_ptr else None, 1 if stream_ptr is None else 0, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def farm_release(self, slot, stream_ptr=None):
+        self._check(self.lib.datum_ocean_farm_release(self.h, slot, P(stream_ptr) if stream_ptr else None, 1 if stream_ptr is None else 0))
+
+    def farm_query(self, slot):
+        rc = self.lib.datum_ocean_farm_query(self.h, slot)
+        if rc == ENOTREADY:
+            return False
+        self._check(rc)
+        return True
+
+    def farm_wait(self, slot):
+        """Host wait for the slot's collective; returns its duration on the communication stream in ms."""
+        ms = F()
+        self._check(self.lib.datum_ocean_farm_wait(self.h, slot, ctypes.byref(ms)))
+        return ms.value
+
     def import_memory_fd(self, fd, nbytes):
         """Device pointer over memory another API exported as a POSIX fd (Vulkan external memory, opaque fd)."""
         p = P()
@@ -316,6 +371,15 @@ class Ocean:
         row, col = D(), D()
         self._check(self.lib.datum_ocean_algorithmic_bytes(self.h, ctypes.byref(row), ctypes.byref(col)))
         return row.value, col.value
+
+
+def farm_unique_id():
+    """The 128-byte id of a new farm communicator (rank 0 makes it, every rank passes it to Ocean.farm_init)."""
+    buf = (ctypes.c_char * FARM_ID_BYTES)()
+    rc = load().datum_ocean_farm_unique_id(buf, FARM_ID_BYTES)
+    if rc != 0:
+        raise OceanError(rc, load().datum_ocean_last_error(None).decode())
+    return bytes(buf)
 
 
 def map_layout(N):

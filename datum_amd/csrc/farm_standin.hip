@@ -24,8 +24,18 @@ namespace
   // dst[peer][...] = src[...] for `peers` peers; workgroup g takes chunks g, g + gridDim.x, ...; after each chunk it waits
   // until the clock has reached what `ticks_per_chunk` allows for the chunks it has moved
   // mode 0: copy; 1: resident only (no memory traffic); 2: reads only; 3: writes only (what arrives over xGMI costs no reads here)
+  // mode 4 / 5 / 6: as 0 / 2 / 3 with NON-TEMPORAL loads and stores (the `nt` bit: streaming data that should not displace what
+  // the caches hold) -- if the step's slowdown under the stand-in is Infinity-Cache eviction it shrinks with these, if it is
+  // plain bandwidth contention it does not (tools/gather_overhead.sh)
+  typedef unsigned int u4_ __attribute__((ext_vector_type(4)));
+
   __global__ void __launch_bounds__(THREADS) standin_kernel(uint4 *dst, uint4 const *src, size_t bytes, int peers, float ticks_per_chunk, int mode)
   {
+    bool const nt = mode >= 4;
+
+    if (nt)
+      mode = (mode == 4) ? 0 : (mode == 5) ? 2 : 3;
+
     size_t const chunks = (bytes + CHUNK - 1) / CHUNK;
     size_t const total = chunks * peers;
     unsigned long long const t0 = realtime();
@@ -40,9 +50,43 @@ namespace
       {
         uint4 v[8];                            // eight loads in flight per lane, then eight stores
 
-        #pragma unroll
-        for(int k = 0; k < 8; ++k)
-          v[k] = (mode == 3) ? make_uint4(k, peer, chunk, 0) : src[first + threadIdx.x + k * THREADS];
+        if (mode == 3)
+        {
+          #pragma unroll
+          for(int k = 0; k < 8; ++k)
+            v[k] = make_uint4(k, peer, chunk, 0);
+        }
+        else if (nt)
+        {
+          // (inline asm, one statement with its own wait: as a builtin the non-temporal load is merged with the plain one of
+          // the other branch)
+          u4_ t[8];
+          uint4 const *at = src + first + threadIdx.x;
+
+          asm volatile("global_load_dwordx4 %0, %8, off offset:-4096 nt\n\t"
+                       "global_load_dwordx4 %1, %8, off nt\n\t"
+                       "global_load_dwordx4 %2, %9, off offset:-4096 nt\n\t"
+                       "global_load_dwordx4 %3, %9, off nt\n\t"
+                       "global_load_dwordx4 %4, %10, off offset:-4096 nt\n\t"
+                       "global_load_dwordx4 %5, %10, off nt\n\t"
+                       "global_load_dwordx4 %6, %11, off offset:-4096 nt\n\t"
+                       "global_load_dwordx4 %7, %11, off nt\n\t"
+                       "s_waitcnt vmcnt(0)"
+                       : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                       : "v"(at + THREADS), "v"(at + 3 * THREADS), "v"(at + 5 * THREADS), "v"(at + 7 * THREADS) : "memory");
+
+          static_assert(THREADS * 16 == 4096, "offset:-4096 is one k step");
+
+          #pragma unroll
+          for(int k = 0; k < 8; ++k)
+            v[k] = __builtin_bit_cast(uint4, t[k]);
+        }
+        else
+        {
+          #pragma unroll
+          for(int k = 0; k < 8; ++k)
+            v[k] = src[first + threadIdx.x + k * THREADS];
+        }
 
         if (mode == 2)
         {
@@ -57,9 +101,18 @@ namespace
         }
         else
         {
-          #pragma unroll
-          for(int k = 0; k < 8; ++k)
-            dst[peer * (bytes / 16) + first + threadIdx.x + k * THREADS] = v[k];
+          if (nt)
+          {
+            #pragma unroll
+            for(int k = 0; k < 8; ++k)
+              __builtin_nontemporal_store(__builtin_bit_cast(u4_, v[k]), reinterpret_cast<u4_*>(dst) + peer * (bytes / 16) + first + threadIdx.x + k * THREADS);
+          }
+          else
+          {
+            #pragma unroll
+            for(int k = 0; k < 8; ++k)
+              dst[peer * (bytes / 16) + first + threadIdx.x + k * THREADS] = v[k];
+          }
         }
       }
       else if (mode == 1)

@@ -16,6 +16,7 @@
 
 #include "ocean_kernels.hip"
 #include "ocean_gen.hip"
+#include "ocean_farm.hip"
 
 using namespace ocean;
 
@@ -57,6 +58,8 @@ struct datum_ocean_ctx
   struct ImportedMemory { hipExternalMemory_t memory; void *ptr; size_t bytes; };
   std::vector<ImportedMemory> importedmemory;
   std::vector<hipExternalSemaphore_t> importedsemaphores;
+
+  ocean::Farm *farm = nullptr;        // the tile farm's communicator, stream and double-buffered payload (datum_ocean_farm_init)
 
   // profiling
   bool profiling = false;
@@ -348,6 +351,76 @@ namespace
 
     return DATUM_OCEAN_OK;
   }
+
+  // the pack of datum_ocean_pack_displacement / datum_ocean_farm_gather, on the handle's stream (arguments checked by the callers)
+  int pack_into(datum_ocean_ctx *ctx, int format, void *payload_device, size_t need)
+  {
+    if (format == DATUM_OCEAN_PAYLOAD_MAPS)
+    {
+      // the map block as it lies in memory (device layout), so that the producer may go on writing its own buffer
+      HIPCHECK(ctx, hipMemcpyAsync(payload_device, ctx->maps, need, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    else
+    {
+      int const blocks = std::min<size_t>((size_t)ctx->cus * 8, ((size_t)ctx->cascades * plane(ctx) / 4 + 255) / 256);
+
+      if (format == DATUM_OCEAN_PAYLOAD_XYZ16)
+        hipLaunchKernelGGL(ocean_pack_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device);
+      else
+        hipLaunchKernelGGL(ocean_pack_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device);
+
+      HIPCHECK(ctx, hipGetLastError());
+    }
+
+    return DATUM_OCEAN_OK;
+  }
+
+  // an ncclResult_t never leaves the module
+  int fail_comm(datum_ocean_ctx *ctx, ocean::RcclApi *api, ncclComm_t comm, ncclResult_t r, char const *what)
+  {
+    char buf[768];
+
+    char const *last = (api && api->GetLastError) ? api->GetLastError(comm) : "";
+
+    snprintf(buf, sizeof(buf), "%s: %s (ncclResult %d)%s%s", what, (api && api->GetErrorString) ? api->GetErrorString(r) : "?", (int)r, (last && *last) ? ": " : "", (last && *last) ? last : "");
+
+    (ctx ? ctx->error : g_error) = buf;
+
+    return DATUM_OCEAN_ECOMM;
+  }
+
+  #define RCCLCHECK(ctx, api, comm, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return fail_comm(ctx, api, comm, r_, #call); } while(0)
+
+  void farm_teardown(datum_ocean_ctx *ctx)
+  {
+    ocean::Farm *f = ctx->farm;
+
+    if (!f)
+      return;
+
+    if (f->stream)
+      (void)hipStreamSynchronize(f->stream);
+
+    if (f->comm && f->api)
+      (void)f->api->CommDestroy(f->comm);
+
+    for(auto &sl : f->slots)
+    {
+      (void)hipFree(sl.payload);
+      (void)hipFree(sl.gathered);
+
+      for(hipEvent_t e : { sl.packed, sl.start, sl.done, sl.consumed })
+        if (e)
+          (void)hipEventDestroy(e);
+    }
+
+    if (f->stream)
+      (void)hipStreamDestroy(f->stream);
+
+    delete f;
+
+    ctx->farm = nullptr;
+  }
 }
 
 extern "C"
@@ -460,6 +533,8 @@ int datum_ocean_destroy(datum_ocean_t ctx)
 
   if (ctx->stream)
     (void)hipStreamSynchronize(ctx->stream);
+
+  farm_teardown(ctx);
 
   for(hipEvent_t e : ctx->events)
     (void)hipEventDestroy(e);
@@ -943,22 +1018,293 @@ int datum_ocean_pack_displacement(datum_ocean_t ctx, int format, void *payload_d
 
   HIPCHECK(ctx, hipSetDevice(ctx->device));
 
-  if (format == DATUM_OCEAN_PAYLOAD_MAPS)
-  {
-    // the map block as it lies in memory (device layout), so that the producer may go on writing its own buffer
-    HIPCHECK(ctx, hipMemcpyAsync(payload_device, ctx->maps, need, hipMemcpyDeviceToDevice, ctx->stream));
-  }
-  else
-  {
-    int const blocks = std::min<size_t>((size_t)ctx->cus * 8, ((size_t)ctx->cascades * plane(ctx) / 4 + 255) / 256);
+  return pack_into(ctx, format, payload_device, need);
+}
 
-    if (format == DATUM_OCEAN_PAYLOAD_XYZ16)
-      hipLaunchKernelGGL(ocean_pack_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device);
-    else
-      hipLaunchKernelGGL(ocean_pack_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device);
+/* -- the tile farm ------------------------------------------------------------------------------------------------------ */
 
-    HIPCHECK(ctx, hipGetLastError());
+int datum_ocean_farm_unique_id(void *id, size_t bytes)
+{
+  if (!id || bytes != DATUM_OCEAN_FARM_ID_BYTES)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_farm_unique_id: the id is DATUM_OCEAN_FARM_ID_BYTES bytes");
+
+  static_assert(sizeof(ncclUniqueId) == DATUM_OCEAN_FARM_ID_BYTES, "ncclUniqueId");
+
+  std::string why;
+  RcclApi *api = rccl_api(&why);
+
+  if (!api)
+    return fail(nullptr, DATUM_OCEAN_EUNSUPPORTED, ("datum_ocean_farm_unique_id: no RCCL library could be opened: " + why).c_str());
+
+  ncclUniqueId uid;
+
+  RCCLCHECK(nullptr, api, nullptr, api->GetUniqueId(&uid));
+
+  memcpy(id, &uid, sizeof(uid));
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_farm_init(datum_ocean_t ctx, void const *id, size_t idbytes, int rank, int world, int format, int slots)
+{
+  if (!ctx || !id || idbytes != DATUM_OCEAN_FARM_ID_BYTES)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_farm_init: null argument, or an id that is not DATUM_OCEAN_FARM_ID_BYTES bytes");
+
+  if (world < 1 || rank < 0 || rank >= world)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_farm_init: rank outside [0, world)");
+
+  if (slots < 1 || slots > 8)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_farm_init: 1 to 8 slots (2 = double-buffered)");
+
+  if (ctx->farm)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_farm_init: the handle already farms (datum_ocean_farm_shutdown first)");
+
+  size_t bytes = 0;
+
+  int rc = datum_ocean_payload_bytes(ctx, format, &bytes);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  std::string why;
+  RcclApi *api = rccl_api(&why);
+
+  if (!api)
+    return fail(ctx, DATUM_OCEAN_EUNSUPPORTED, ("datum_ocean_farm_init: no RCCL library could be opened: " + why).c_str());
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  Farm *f = new (std::nothrow) Farm;
+  if (!f)
+    return fail(ctx, DATUM_OCEAN_ENOMEM, "datum_ocean_farm_init: out of host memory");
+
+  ctx->farm = f;
+
+  f->api = api;
+  f->rank = rank;
+  f->world = world;
+  f->format = format;
+  f->bytes = bytes;
+
+  #define FARMCHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int rc_ = fail(ctx, (int)e_, #call); farm_teardown(ctx); return rc_; } } while(0)
+
+  FARMCHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+
+  f->slots.resize(slots);
+
+  for(auto &sl : f->slots)
+  {
+    FARMCHECK(hipMalloc(&sl.payload, bytes));
+    FARMCHECK(hipMalloc(&sl.gathered, bytes * world));
+    FARMCHECK(hipEventCreateWithFlags(&sl.packed, hipEventDisableTiming));
+    FARMCHECK(hipEventCreate(&sl.start));
+    FARMCHECK(hipEventCreate(&sl.done));
+    FARMCHECK(hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
   }
+
+  #undef FARMCHECK
+
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+
+  // (collective over the ranks: returns when every rank of the farm has called it)
+  ncclResult_t r = api->CommInitRank(&f->comm, world, uid, rank);
+
+  if (r != ncclSuccess)
+  {
+    int rc_ = fail_comm(ctx, api, nullptr, r, "ncclCommInitRank");
+    f->comm = nullptr;
+    farm_teardown(ctx);
+    return rc_;
+  }
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_farm_shutdown(datum_ocean_t ctx)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_farm_shutdown: null handle");
+
+  (void)hipSetDevice(ctx->device);
+
+  farm_teardown(ctx);
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_farm_info(datum_ocean_t ctx, int *rank, int *world, int *format, size_t *payload_bytes, int *slots, int *rccl_version)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_farm_info: null handle");
+
+  if (!ctx->farm)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_farm_info: datum_ocean_farm_init first");
+
+  Farm const *f = ctx->farm;
+
+  if (rank) *rank = f->rank;
+  if (world) *world = f->world;
+  if (format) *format = f->format;
+  if (payload_bytes) *payload_bytes = f->bytes;
+  if (slots) *slots = (int)f->slots.size();
+
+  if (rccl_version)
+  {
+    *rccl_version = 0;
+    (void)f->api->GetVersion(rccl_version);
+  }
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_farm_gather(datum_ocean_t ctx, int *slot)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_farm_gather: null handle");
+
+  if (!ctx->farm)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_farm_gather: datum_ocean_farm_init first");
+
+  Farm *f = ctx->farm;
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  int const s = f->head;
+  FarmSlot &sl = f->slots[s];
+
+  // WAR on the payload: the collective that last READ this slot's payload must have finished before the pack overwrites it
+  if (sl.launched)
+    HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, sl.done, 0));
+
+  // the pack, on the handle's stream behind the last displace
+  int rc = pack_into(ctx, f->format, sl.payload, f->bytes);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  HIPCHECK(ctx, hipEventRecord(sl.packed, ctx->stream));
+
+  // the collective, on the communication stream: behind the pack, and behind the consumer that may still read gathered[s]
+  HIPCHECK(ctx, hipStreamWaitEvent(f->stream, sl.packed, 0));
+
+  if (sl.busy)
+  {
+    HIPCHECK(ctx, hipStreamWaitEvent(f->stream, sl.consumed, 0));
+    sl.busy = false;
+  }
+
+  HIPCHECK(ctx, hipEventRecord(sl.start, f->stream));
+
+  RCCLCHECK(ctx, f->api, f->comm, f->api->AllGather(sl.payload, sl.gathered, f->bytes, ncclInt8, f->comm, f->stream));
+
+  HIPCHECK(ctx, hipEventRecord(sl.done, f->stream));
+
+  sl.launched = true;
+
+  f->head = (s + 1) % (int)f->slots.size();
+  f->gathers += 1;
+
+  if (slot)
+    *slot = s;
+
+  return DATUM_OCEAN_OK;
+}
+
+namespace
+{
+  static int farm_slot(datum_ocean_ctx *ctx, int slot, char const *who, FarmSlot **out)
+  {
+    if (!ctx)
+      return fail(nullptr, DATUM_OCEAN_EINVAL, who);
+
+    if (!ctx->farm)
+      return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_farm_*: datum_ocean_farm_init first");
+
+    if (slot < 0 || slot >= (int)ctx->farm->slots.size())
+      return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_farm_*: no such slot");
+
+    if (!ctx->farm->slots[slot].launched)
+      return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_farm_*: nothing was gathered into this slot yet");
+
+    *out = &ctx->farm->slots[slot];
+
+    return DATUM_OCEAN_OK;
+  }
+}
+
+int datum_ocean_farm_result(datum_ocean_t ctx, int slot, void *hip_stream, int on_handle_stream, void **gathered_device, size_t *bytes)
+{
+  FarmSlot *sl = nullptr;
+
+  int rc = farm_slot(ctx, slot, "datum_ocean_farm_result: null handle", &sl);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  if (!gathered_device)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_farm_result: null argument");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamWaitEvent(on_handle_stream ? ctx->stream : (hipStream_t)hip_stream, sl->done, 0));
+
+  *gathered_device = sl->gathered;
+
+  if (bytes)
+    *bytes = ctx->farm->bytes * ctx->farm->world;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_farm_release(datum_ocean_t ctx, int slot, void *hip_stream, int on_handle_stream)
+{
+  FarmSlot *sl = nullptr;
+
+  int rc = farm_slot(ctx, slot, "datum_ocean_farm_release: null handle", &sl);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipEventRecord(sl->consumed, on_handle_stream ? ctx->stream : (hipStream_t)hip_stream));
+
+  sl->busy = true;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_farm_query(datum_ocean_t ctx, int slot)
+{
+  FarmSlot *sl = nullptr;
+
+  int rc = farm_slot(ctx, slot, "datum_ocean_farm_query: null handle", &sl);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  hipError_t const e = hipEventQuery(sl->done);
+
+  if (e == hipErrorNotReady)
+  {
+    (void)hipGetLastError();
+    return DATUM_OCEAN_ENOTREADY;
+  }
+
+  HIPCHECK(ctx, e);
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_farm_wait(datum_ocean_t ctx, int slot, float *collective_ms)
+{
+  FarmSlot *sl = nullptr;
+
+  int rc = farm_slot(ctx, slot, "datum_ocean_farm_wait: null handle", &sl);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipEventSynchronize(sl->done));
+
+  if (collective_ms)
+    HIPCHECK(ctx, hipEventElapsedTime(collective_ms, sl->start, sl->done));
 
   return DATUM_OCEAN_OK;
 }
@@ -1179,7 +1525,7 @@ int datum_ocean_import_semaphore_fd(datum_ocean_t ctx, int fd, void **semaphore)
 
 namespace
 {
-  bool owns_semaphore(datum_ocean_ctx *ctx, void *semaphore)
+  static bool owns_semaphore(datum_ocean_ctx *ctx, void *semaphore)
   {
     for(hipExternalSemaphore_t s : ctx->importedsemaphores)
       if (s == semaphore)

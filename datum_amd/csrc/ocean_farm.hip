@@ -1,0 +1,126 @@
+// ocean_farm.hip -- the tile farm's one exchange step inside the C ABI: an RCCL all-gather of every rank's displacement
+// field (north_star: "independent ocean cascades/tiles farm across the 8 GPUs of one node with a single RCCL
+// all-gather over xGMI to reassemble the displacement field").  Nothing in the reference corresponds to it (one device).
+//
+// A C++ renderer that runs one process per GPU needs nothing but this module: rank 0 makes the 128-byte id
+// (datum_ocean_farm_unique_id), hands it to the other ranks by whatever channel the host has, every rank calls
+// datum_ocean_farm_init on its handle, and from then on
+//
+//     slot = farm_gather(ctx)                      pack (handle's stream, behind the last displace) + all-gather (the module's
+//                                                  communication stream); returns at once: the next steps' kernels overlap it
+//     farm_result(ctx, slot, stream, ...)          `stream` waits for that collective; pointer to the gathered block
+//     farm_release(ctx, slot, stream)              `stream` is done reading: the slot's next collective waits for this point
+//
+// The payload and the gathered block are double-buffered (slots), every ordering is an event between streams, no call blocks
+// the host except farm_wait.  RCCL is opened with dlopen at farm_init: a renderer that never farms has no dependency on it,
+// and a process that already holds an RCCL (PyTorch's) shares that one instead of mapping a second copy.
+//
+// The choreography mirrors datum_amd/farm.py's TileGather, which stays as its CPU model (tests/test_farm_gloo.py: gloo,
+// world sizes 2 and 8).
+
+#pragma once
+
+#include <dlfcn.h>
+
+#include <rccl/rccl.h>
+
+namespace ocean
+{
+  struct RcclApi
+  {
+    void *lib = nullptr;
+    std::string path;
+
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(void const*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    char const *(*GetErrorString)(ncclResult_t) = nullptr;
+    char const *(*GetLastError)(ncclComm_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+  };
+
+  // one per process; the first farm call opens it
+  inline RcclApi *rccl_api(std::string *why)
+  {
+    static RcclApi api;
+    static std::string failure;
+    static bool tried = false;
+
+    if (!tried)
+    {
+      tried = true;
+
+      char const *names[] = { getenv("DATUM_OCEAN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+
+      for(char const *name : names)
+      {
+        if (!name || !*name)
+          continue;
+
+        // (RTLD_NOLOAD first: the copy the process already holds, e.g. PyTorch's, whatever directory it came from)
+        void *lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+
+        if (!lib)
+          lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+
+        if (lib)
+        {
+          api.lib = lib;
+          api.path = name;
+          break;
+        }
+
+        failure += std::string(failure.empty() ? "" : "; ") + dlerror();
+      }
+
+      if (api.lib)
+      {
+        #define OCEAN_RCCL_SYM(field, symbol) do { *reinterpret_cast<void**>(&api.field) = dlsym(api.lib, symbol); if (!api.field) { failure = std::string("RCCL library lacks ") + symbol; api.lib = nullptr; } } while(0)
+        OCEAN_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+        OCEAN_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+        OCEAN_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+        OCEAN_RCCL_SYM(AllGather, "ncclAllGather");
+        OCEAN_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+        OCEAN_RCCL_SYM(GetLastError, "ncclGetLastError");
+        OCEAN_RCCL_SYM(GetVersion, "ncclGetVersion");
+        #undef OCEAN_RCCL_SYM
+      }
+    }
+
+    if (!api.lib)
+    {
+      if (why)
+        *why = failure;
+
+      return nullptr;
+    }
+
+    return &api;
+  }
+
+  struct FarmSlot
+  {
+    void *payload = nullptr;          // this rank's contribution (written by the pack on the handle's stream)
+    void *gathered = nullptr;         // world x payload, ordered by rank (written by the collective on the communication stream)
+    hipEvent_t packed = nullptr;      // behind the pack
+    hipEvent_t start = nullptr;       // around the collective (timing)
+    hipEvent_t done = nullptr;
+    hipEvent_t consumed = nullptr;    // recorded by farm_release on the consumer's stream
+    bool launched = false;            // a collective has been enqueued into this slot
+    bool busy = false;                // ... and its consumer has not released it yet (consumed is armed)
+  };
+
+  struct Farm
+  {
+    RcclApi *api = nullptr;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;     // the communication stream
+    int rank = 0, world = 1;
+    int format = DATUM_OCEAN_PAYLOAD_XYZ32;
+    size_t bytes = 0;                 // payload bytes per rank
+    std::vector<FarmSlot> slots;
+    int head = 0;                     // next slot
+    unsigned long gathers = 0;
+  };
+}

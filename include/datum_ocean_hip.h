@@ -40,6 +40,7 @@ enum
   DATUM_OCEAN_ENOMEM = -3,
   DATUM_OCEAN_EUNSUPPORTED = -4,  /* the HIP runtime on this machine lacks the feature (external semaphores on ROCm 7.0.x: use the
                                    host bridge, datum_ocean_on_complete / datum_ocean_query)                                  */
+  DATUM_OCEAN_ECOMM = -6,         /* an RCCL call of the tile farm failed (datum_ocean_last_error has RCCL's own text)          */
   DATUM_OCEAN_ENOTREADY = -5      /* datum_ocean_query / datum_ocean_farm_query only: the work is still running (not a failure).
                                    A module code, because every positive return value is a hipError_t (hipErrorInvalidValue
                                    is 1) and a poller must be able to tell "not yet" from "the query itself failed"         */
@@ -162,6 +163,39 @@ int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, 
 #define DATUM_OCEAN_PAYLOAD_XYZ16 2
 int datum_ocean_payload_bytes(datum_ocean_t ctx, int format, size_t *bytes);
 int datum_ocean_pack_displacement(datum_ocean_t ctx, int format, void *payload_device, size_t bytes);
+
+/* -- the tile farm: N processes, one GPU each, independent tiles / cascades, ONE all-gather per batch ------------------
+ * (nothing in the reference, which has one device.)  The displacement step needs no exchange; what
+ * north_star's "single RCCL all-gather over xGMI" reassembles is the displacement field of every rank's grids.  These
+ * entry points own that step, so a C++ renderer farms tiles with this module alone: the RCCL communicator, a communication
+ * stream, `slots` payload buffers (this rank's packed displacement, datum_ocean_pack_displacement's formats) and `slots`
+ * gathered buffers (world x payload, ordered by rank), and the event choreography between them.
+ *
+ *   unique_id   rank 0 only: the 128-byte id of a new communicator; hand it to every rank (a pipe, a file, MPI, a socket)
+ *   init        every rank, same id / world / format / slots: creates the communicator (blocks until all ranks have called)
+ *   gather      enqueue and return: on the handle's stream, behind the last displace, the pack into the next slot's payload
+ *               (first waiting, on the device, for the collective that last read that payload); on the communication stream,
+ *               behind the pack and behind the slot's last release, ncclAllGather into the slot's gathered buffer.  The
+ *               following displace calls overlap the collective.  *slot = which slot.
+ *   result      `hip_stream` (or the handle's own stream when on_handle_stream != 0) waits for the slot's collective;
+ *               *gathered_device = world x payload_bytes bytes, rank r's payload at r * payload_bytes
+ *   release     `hip_stream` (or the handle's) has finished reading the gathered buffer up to this point: the slot's next
+ *               collective waits for it.  Needed whenever a consumer reads on a stream of its own.
+ *   query       DATUM_OCEAN_OK once the slot's collective has finished, DATUM_OCEAN_ENOTREADY before; never blocks
+ *   wait        blocks the host until it has; *collective_ms (may be NULL) = its duration on the communication stream
+ *   shutdown    destroys communicator, stream and buffers (datum_ocean_destroy does it too)
+ * RCCL is opened with dlopen at the first farm call (DATUM_OCEAN_RCCL_LIB, librccl.so.1): DATUM_OCEAN_EUNSUPPORTED when no
+ * library is found; an ncclResult_t is reported as DATUM_OCEAN_ECOMM with RCCL's text in datum_ocean_last_error. */
+#define DATUM_OCEAN_FARM_ID_BYTES 128
+int datum_ocean_farm_unique_id(void *id, size_t bytes);
+int datum_ocean_farm_init(datum_ocean_t ctx, void const *id, size_t bytes, int rank, int world, int format, int slots);
+int datum_ocean_farm_shutdown(datum_ocean_t ctx);
+int datum_ocean_farm_info(datum_ocean_t ctx, int *rank, int *world, int *format, size_t *payload_bytes, int *slots, int *rccl_version);
+int datum_ocean_farm_gather(datum_ocean_t ctx, int *slot);
+int datum_ocean_farm_result(datum_ocean_t ctx, int slot, void *hip_stream, int on_handle_stream, void **gathered_device, size_t *bytes);
+int datum_ocean_farm_release(datum_ocean_t ctx, int slot, void *hip_stream, int on_handle_stream);
+int datum_ocean_farm_query(datum_ocean_t ctx, int slot);
+int datum_ocean_farm_wait(datum_ocean_t ctx, int slot, float *collective_ms);
 
 /* blocking read-backs (host pointers).  maps: 2*N*N*4 floats. */
 int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps);

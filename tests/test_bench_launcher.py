@@ -19,7 +19,7 @@ def _env(**extra):
     return env
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])      # 8 = BASELINE.json configs[3]'s node
 def test_own_launcher_starts_n_ranks(world):
     r = subprocess.run([sys.executable, BENCH, "--gpus", str(world), "--plumbing"], env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]

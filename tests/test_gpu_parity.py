@@ -842,6 +842,106 @@ def test_pack_displacement_payloads(capi, oracle, torch, N, C):
             assert e.value.code == capi.EINVAL
 
 
+def test_native_farm_one_rank(capi, oracle, torch):
+    # The tile farm inside the C ABI (datum_ocean_farm_*: RCCL communicator, communication stream, double-buffered payload and
+    # event choreography owned by the module -- no torch.distributed).  A one-rank communicator (one box has one GPU):
+    # every batch's gathered displacement equals that batch's read-back although the next batch's kernels overwrite the maps
+    # while the collective is in flight; a consumer on ANOTHER stream reads slowly and farm_release orders the slot's next
+    # collective behind it; query / wait / info / error codes.
+    from datum_amd import farm
+
+    for fmt in ("xyz32", "xyz16", "maps"):
+        N, C = 256, 2
+        p = oracle.EXAMPLE
+        code, dtype, per = farm.PAYLOADS[fmt]
+        stream, consumer = torch.cuda.Stream(), torch.cuda.Stream()
+        with capi.Ocean(N, C) as oc, torch.cuda.stream(stream):
+            oc.set_stream(stream.cuda_stream)
+            for c in range(C):
+                oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c], p["choppiness"])
+                oc.upload_state(c, make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c]))
+            with pytest.raises(capi.OceanError) as e:
+                oc.farm_gather()                                  # before farm_init
+            assert e.value.code == capi.ESTATE
+            uid = capi.farm_unique_id()
+            with pytest.raises(capi.OceanError) as e:
+                oc.farm_init(uid, 1, 1, code)                     # rank outside [0, world)
+            assert e.value.code == capi.EINVAL
+            oc.farm_init(uid, 0, 1, code, slots=2)
+            with pytest.raises(capi.OceanError) as e:
+                oc.farm_init(uid, 0, 1, code)                     # twice
+            assert e.value.code == capi.ESTATE
+            info = oc.farm_info()
+            nbytes = oc.payload_bytes(code)
+            assert (info["rank"], info["world"], info["format"], info["payload_bytes"], info["slots"]) == (0, 1, code, nbytes, 2)
+            assert info["rccl_version"] > 20000
+            with pytest.raises(capi.OceanError) as e:
+                oc.farm_result(1)                                 # nothing gathered into that slot yet
+            assert e.value.code == capi.ESTATE
+            numel = farm.payload_numel(N, C, fmt)
+            want, got, sums = [], [], []
+            prev = None
+            for b in range(6):
+                for _ in range(3):
+                    oc.update(DT)
+                    oc.displace()
+                slot = oc.farm_gather()
+                assert slot == b % 2
+                if prev is not None:
+                    # batch b - 1 on the consumer's own stream, slowly, while batch b's collective and batch b + 1's kernels run
+                    ptr, n = oc.farm_result(prev, consumer.cuda_stream)
+                    assert n == nbytes
+                    with torch.cuda.stream(consumer):
+                        view = _device_view(torch, ptr, numel, dtype)
+                        acc = torch.zeros((), dtype=torch.float64, device="cuda:0")
+                        for _ in range(20):
+                            acc = acc + view.double().abs().sum()
+                        sums.append(acc)
+                        got.append(view.clone())
+                    oc.farm_release(prev, consumer.cuda_stream)
+                prev = slot
+                if fmt == "maps":
+                    raw, _ = oc.maps_device()
+                    want.append(_device_view(torch, raw, numel, dtype).clone())       # the map block as it lies in memory
+                else:
+                    want.append(np.stack([oc.read_maps(c)[0, ..., :3] for c in range(C)]))   # (read-back syncs the compute stream only)
+            ptr, n = oc.farm_result(prev)                          # the last batch on the handle's own stream
+            got.append(_device_view(torch, ptr, numel, dtype).clone())
+            ms = oc.farm_wait(prev)
+            assert ms >= 0.0 and oc.farm_query(prev) is True
+            consumer.synchronize()
+            stream.synchronize()
+            for b in range(6):
+                if fmt == "maps":
+                    assert torch.equal(got[b], want[b]), (fmt, b)
+                else:
+                    for c in range(C):
+                        d = farm.view_displacement(got[b].cpu(), N, c, fmt)
+                        ref = torch.from_numpy(want[b][c])
+                        assert torch.equal(d, ref if fmt == "xyz32" else ref.to(torch.float16)), (fmt, b, c)
+            for b in range(5):
+                assert abs(float(sums[b]) - 20 * float(got[b].double().abs().sum())) <= 1e-9 * abs(float(sums[b])) + 1e-12, (fmt, b)
+            oc.farm_shutdown()
+            with pytest.raises(capi.OceanError) as e:
+                oc.farm_gather()
+            assert e.value.code == capi.ESTATE
+            oc.farm_init(capi.farm_unique_id(), 0, 1, code)       # and again after a shutdown; destroy tears it down
+            oc.farm_gather()
+            oc.set_stream(None)
+
+
+def _device_view(torch, ptr, numel, dtype):
+    """A torch tensor over device memory the module owns (no copy): __cuda_array_interface__ of a raw pointer."""
+
+    class _Raw:
+        pass
+
+    r = _Raw()
+    item = torch.empty(0, dtype=dtype).element_size()
+    r.__cuda_array_interface__ = {"shape": (numel,), "typestr": {2: "<f2", 4: "<f4"}[item], "data": (ptr, False), "version": 2}
+    return torch.as_tensor(r, device="cuda:0")
+
+
 def test_tile_gather_on_device(capi, oracle, torch):
     # datum_amd/farm.TileGather on the GPU with a real RCCL collective (a one-rank process group: one box has one GPU):
     # pack on the compute stream, all-gather on the communication stream, event-ordered, while the next batch's kernels

@@ -26,6 +26,9 @@ run --force-collective --payload xyz32 --gather-every 1
 done
 echo "== which part of the stand-in costs the step (32 workgroups, paced to 300 GB/s = 1.18 ms resident, xyz32)"
 for m in 0 1 2 3; do echo "  mode $m (0 copy, 1 resident only, 2 reads only, 3 writes only):"; DATUM_STANDIN_MODE=$m run --standin-peers 7 --payload xyz32 --standin-workgroups 32 --standin-gbps 300; done
+echo "== the same with non-temporal loads / stores in the stand-in (cache eviction or bandwidth contention?)"
+for m in 4 5 6; do echo "  mode $m (4 copy nt, 5 reads only nt, 6 writes only nt):"; DATUM_STANDIN_MODE=$m run --standin-peers 7 --payload xyz32 --standin-workgroups 32 --standin-gbps 300; done
+for m in 0 4; do echo "  mode $m unpaced (as fast as HBM takes it):"; DATUM_STANDIN_MODE=$m run --standin-peers 7 --payload xyz32 --standin-workgroups 32 --standin-gbps 0; done
 echo "  mode 1 with 256 workgroups:"; DATUM_STANDIN_MODE=1 run --standin-peers 7 --payload xyz32 --standin-workgroups 256 --standin-gbps 300
 echo "  200-step batches:"; STEPS=200 WARM=20 run; STEPS=200 WARM=20 run --standin-peers 7 --payload xyz32 --standin-workgroups 32 --standin-gbps 300
 echo "== configs[3] share: 2048^2 x 1"
