@@ -186,8 +186,18 @@ def cpu_baseline(N, cascades, budget):
     Vulkan / lavapipe / glslang / leap: DESIGN.md)."""
     import subprocess
 
-    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
-    env.pop("OMP_NUM_THREADS", None)
+    # the cores this process may really use: its affinity mask, capped by the cgroup's CPU quota (a GPU box shows 256 logical
+    # CPUs and grants 16 of them: 256 pinned threads inside a 16-CPU quota ran at 0.66 grids/s, profiles/r04_cpu_baseline.txt)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(period)))
+            cores = min(cores, quota)
+    except Exception:  # noqa: BLE001
+        pass
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_NUM_THREADS=str(cores))
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(N), str(cascades), str(budget)],
                              env=env, capture_output=True, text=True, timeout=max(120.0, 10.0 * budget))
@@ -195,7 +205,8 @@ def cpu_baseline(N, cascades, budget):
     except Exception as e:  # noqa: BLE001
         return dict(value=None, unit="grids/s", cores=None, kind="port", lavapipe=lavapipe_probe(N), sample=f"the child process failed: {e}")
     return dict(value=j["value"], unit="grids/s", cores=j["omp_max_threads"], kind="port", lavapipe=lavapipe_probe(N),
-                host={"omp_get_max_threads": j["omp_max_threads"], "os.cpu_count": j["cpu_count"], "sched_getaffinity": j["affinity"],
+                host={"omp_get_max_threads": j["omp_max_threads"], "os.cpu_count": j["cpu_count"], "sched_getaffinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                      "cgroup_cpu_quota": quota,
                       "OMP_PROC_BIND": j["omp_proc_bind"], "OMP_PLACES": j["omp_places"]},
                 runs_grids_per_s=j["runs_grids_per_s"],
                 sample=f"best of three runs: {j['grids']} grids = {j['grids'] // cascades} steps of {N}x{N} x {cascades} cascades in {j['seconds']:.1f} s, "
@@ -348,7 +359,7 @@ def main():
         del p
 
     # maps land in a torch tensor so that RCCL can gather them in place; kernels run on torch's stream
-    maps = torch.empty(C * 2 * N * N * 4, dtype=torch.float32, device=dev)
+    maps = torch.empty(C * capi.map_block_floats(N), dtype=torch.float32, device=dev)
     oc.bind_maps(maps.data_ptr(), maps.numel() * 4)
     stream = torch.cuda.Stream(dev)   # a real (non-default) stream: events and RCCL below are ordered on it too
     torch.cuda.set_stream(stream)
@@ -555,7 +566,7 @@ def main():
 
     if rank == 0:
         # sanity: the maps of the last step are finite and non-trivial
-        chk = capi.map_layers(maps[: 2 * N * N * 4], N)
+        chk = capi.map_layers(maps[: capi.map_block_floats(N)], N)
         if not args.no_check:
             assert bool(torch.isfinite(chk).all()) and float(chk[0, ..., 2].abs().max()) > 0
 

@@ -55,7 +55,7 @@ SYMBOLS = {
     "datum_ocean_set_stream": (I, [P, P, I]),
     "datum_ocean_bind_maps": (I, [P, P, ctypes.c_size_t]),
     "datum_ocean_maps_device": (I, [P, ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]),
-    "datum_ocean_map_layout": (I, [I, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(I)]),
+    "datum_ocean_map_layout": (I, [I, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(I)]),
     "datum_ocean_set_cascade": (I, [P, I, F, F]),
     "datum_ocean_set_spectrum_format": (I, [P, I]),
     "datum_ocean_upload_state": (I, [P, I, P, P]),
@@ -383,24 +383,44 @@ def farm_unique_id():
 
 
 def map_layout(N):
-    """(GX, GY, B) of the device map layout at resolution N (include/datum_ocean_hip.h: datum_ocean_bind_maps)."""
-    gx, gy, b = I(), I(), I()
-    rc = load().datum_ocean_map_layout(N, ctypes.byref(gx), ctypes.byref(gy), ctypes.byref(b))
+    """(PW, PH, B, texel_bytes) of the device map layout at resolution N (include/datum_ocean_hip.h: datum_ocean_bind_maps):
+    patches (24-byte layout) or groups (32-byte layout) of PW x PH texels, bands of B columns."""
+    gx, gy, b, tb = I(), I(), I(), I()
+    rc = load().datum_ocean_map_layout(N, ctypes.byref(gx), ctypes.byref(gy), ctypes.byref(b), ctypes.byref(tb))
     if rc != 0:
         raise OceanError(rc, load().datum_ocean_last_error(None).decode())
-    return gx.value, gy.value, b.value
+    return gx.value, gy.value, b.value, tb.value
+
+
+def map_block_floats(N):
+    """floats of one cascade's DEVICE map block"""
+    return N * N * map_layout(N)[3] // 4
 
 
 def map_layers(raw, N):
-    """View of one cascade's DEVICE map block (2*N*N*4 floats as the kernels lay them out: bands of B columns, groups of
-    GX x GY texels, layer 0 of the group then layer 1 of the group -- include/datum_ocean_hip.h) as the reference's
-    logical image [layer][y][x][4].  Works on numpy arrays and torch tensors alike (reshape / permute only)."""
-    GX, GY, B = map_layout(N)
-    v = raw.reshape(N // B, N // GY, B // GX, 2, GY, GX, 4)   # [band][y / GY][group][layer][y % GY][x % GX][component]
-    order = (3, 1, 4, 0, 2, 5, 6)                              # -> [layer][y / GY][y % GY][band][group][x % GX][component]
-    if hasattr(v, "permute"):
-        return v.permute(*order).reshape(2, N, N, 4)
-    return v.transpose(*order).reshape(2, N, N, 4)
+    """One cascade's DEVICE map block (map_block_floats(N) floats as the kernels lay them out, include/datum_ocean_hip.h) as
+    the reference's logical image [layer][y][x][4] (.w = 0).  Works on numpy arrays and torch tensors alike.
+    24-byte layout: bands of B columns, patches of PW x PH texels, 16 x (dx, dy, dz, nx) then 16 x (ny, nz) per patch.
+    32-byte layout: groups of GX x GY texels, layer 0 of the group then layer 1 of the group (reshape / permute only)."""
+    GX, GY, B, TB = map_layout(N)
+    torchlike = hasattr(raw, "permute")
+    if TB == 32:
+        v = raw.reshape(N // B, N // GY, B // GX, 2, GY, GX, 4)   # [band][y / GY][group][layer][y % GY][x % GX][component]
+        order = (3, 1, 4, 0, 2, 5, 6)                              # -> [layer][y / GY][y % GY][band][group][x % GX][component]
+        return (v.permute(*order) if torchlike else v.transpose(*order)).reshape(2, N, N, 4)
+    v = raw.reshape(N // B, N // GY, B // GX, 96)                  # [band][y / PH][patch][96 floats]
+    a = v[..., :64].reshape(N // B, N // GY, B // GX, GY, GX, 4)   # (dx, dy, dz, nx) per texel
+    b = v[..., 64:].reshape(N // B, N // GY, B // GX, GY, GX, 2)   # (ny, nz) per texel
+    order = (1, 3, 0, 2, 4, 5)                                     # -> [y / PH][y % PH][band][patch][x % PW][component]
+    if torchlike:
+        import torch
+
+        a, b = a.permute(*order).reshape(N, N, 4), b.permute(*order).reshape(N, N, 2)
+        z = torch.zeros_like(a[..., :1])
+        return torch.stack([torch.cat([a[..., :3], z], -1), torch.cat([a[..., 3:], b, z], -1)])
+    a, b = a.transpose(*order).reshape(N, N, 4), b.transpose(*order).reshape(N, N, 2)
+    z = np.zeros_like(a[..., :1])
+    return np.stack([np.concatenate([a[..., :3], z], -1), np.concatenate([a[..., 3:], b, z], -1)])
 
 
 def reference_weights(N):

@@ -467,14 +467,14 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
   CREATECHECK(hipMalloc(&ctx->phase, cascades * P * sizeof(float)));
   CREATECHECK(hipMalloc(&ctx->spec, cascades * P * sizeof(cd)));
   CREATECHECK(hipMalloc(&ctx->absmax, sizeof(unsigned int)));
-  CREATECHECK(hipMalloc(&ctx->ownmaps, cascades * 2 * P * sizeof(float4)));
+  CREATECHECK(hipMalloc(&ctx->ownmaps, cascades * map_cascade_bytes(resolution)));
   CREATECHECK(hipMalloc(&ctx->tw, resolution * sizeof(cf)));
   CREATECHECK(hipMalloc(&ctx->omega, (size_t)cascades * (resolution / 2 + 1) * (resolution / 2 + 1) * sizeof(float)));
   ctx->maps = ctx->ownmaps;
 
   CREATECHECK(hipMemsetAsync(ctx->h0, 0, cascades * P * sizeof(float2), ctx->stream));
   CREATECHECK(hipMemsetAsync(ctx->phase, 0, cascades * P * sizeof(float), ctx->stream));
-  CREATECHECK(hipMemsetAsync(ctx->ownmaps, 0, cascades * 2 * P * sizeof(float4), ctx->stream));
+  CREATECHECK(hipMemsetAsync(ctx->ownmaps, 0, cascades * map_cascade_bytes(resolution), ctx->stream));
 
   // exp(+2 pi i k / N), rounded once from double (the reference's table -- ocean.cpp:686-700 -- is per
   // lane and stage and evaluated at unreduced fp32 angles; see datum_ocean_reference_weights)
@@ -584,10 +584,10 @@ int datum_ocean_bind_maps(datum_ocean_t ctx, void *device_ptr, size_t bytes)
   if (!ctx)
     return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_bind_maps: null handle");
 
-  size_t need = ctx->cascades * 2 * plane(ctx) * sizeof(float4);
+  size_t need = ctx->cascades * map_cascade_bytes(ctx->N);
 
   if (device_ptr && bytes < need)
-    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_bind_maps: buffer smaller than cascades*2*N*N*16 bytes");
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_bind_maps: buffer smaller than cascades * N * N * texel_bytes (datum_ocean_map_layout)");
 
   if (device_ptr && ((uintptr_t)device_ptr & 15))
     return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_bind_maps: buffer must be 16-byte aligned");
@@ -608,19 +608,20 @@ int datum_ocean_maps_device(datum_ocean_t ctx, void **device_ptr, size_t *bytes)
   *device_ptr = ctx->maps;
 
   if (bytes)
-    *bytes = ctx->cascades * 2 * plane(ctx) * sizeof(float4);
+    *bytes = ctx->cascades * map_cascade_bytes(ctx->N);
 
   return DATUM_OCEAN_OK;
 }
 
-int datum_ocean_map_layout(int resolution, int *group_cols, int *group_rows, int *band)
+int datum_ocean_map_layout(int resolution, int *group_cols, int *group_rows, int *band, int *texel_bytes)
 {
-  if (!supported(resolution) || !group_cols || !group_rows || !band)
+  if (!supported(resolution) || !group_cols || !group_rows || !band || !texel_bytes)
     return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_map_layout: bad argument");
 
-  *group_cols = map_group_cols(resolution);
-  *group_rows = map_group_rows(resolution);
+  *group_cols = MAP_COMPACT ? map_patch_cols(resolution) : map_group_cols(resolution);
+  *group_rows = MAP_COMPACT ? map_patch_rows(resolution) : map_group_rows(resolution);
   *band = band_cols(resolution);
+  *texel_bytes = MAP_COMPACT ? 24 : 32;
 
   return DATUM_OCEAN_OK;
 }
@@ -972,7 +973,7 @@ int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, 
 
   GenArgs g;
   g.set = *set;
-  g.map = ctx->maps + (size_t)cascade * 2 * plane(ctx);
+  g.map = reinterpret_cast<float4 const*>(reinterpret_cast<char const*>(ctx->maps) + (size_t)cascade * map_cascade_bytes(ctx->N));
   g.vertices = (float*)vertices_device;
   gen_shape(g, ctx->N, sizex, sizey);
 
@@ -990,7 +991,7 @@ int datum_ocean_payload_bytes(datum_ocean_t ctx, int format, size_t *bytes)
 
   switch(format)
   {
-    case DATUM_OCEAN_PAYLOAD_MAPS: *bytes = points * 2 * sizeof(float4); break;
+    case DATUM_OCEAN_PAYLOAD_MAPS: *bytes = (size_t)ctx->cascades * map_cascade_bytes(ctx->N); break;
     case DATUM_OCEAN_PAYLOAD_XYZ32: *bytes = points * 12; break;
     case DATUM_OCEAN_PAYLOAD_XYZ16: *bytes = points * 8; break;
     default: return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_payload_bytes: unknown format");
@@ -1321,21 +1322,40 @@ int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps)
 
   size_t const P = plane(ctx);
 
-  // the device layout interleaves the layers in groups of four texels (ocean_kernels.hip: map_index); hand out the
-  // reference's logical image, [layer][y][x]
-  std::vector<float4> raw;
-  try { raw.resize(2 * P); } catch (...) { return fail(ctx, DATUM_OCEAN_ENOMEM, "datum_ocean_read_maps: out of host memory"); }
+  // the device layout is the module's own (ocean_kernels.hip: map_compact_a / map_index); hand out the reference's logical
+  // image, [layer][y][x] RGBA32F with the .w channels zero (map.comp:79-80)
+  size_t const bytes = map_cascade_bytes(ctx->N);
 
-  HIPCHECK(ctx, hipMemcpyAsync(raw.data(), ctx->maps + (size_t)cascade * 2 * P, 2 * P * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<float> raw;
+  try { raw.resize(bytes / sizeof(float)); } catch (...) { return fail(ctx, DATUM_OCEAN_ENOMEM, "datum_ocean_read_maps: out of host memory"); }
+
+  HIPCHECK(ctx, hipMemcpyAsync(raw.data(), reinterpret_cast<char const*>(ctx->maps) + (size_t)cascade * bytes, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
 
   int const N = ctx->N;
   float4 *out = reinterpret_cast<float4*>(maps);
 
-  for(int layer = 0; layer < 2; ++layer)
-    for(int y = 0; y < N; ++y)
-      for(int x = 0; x < N; ++x)
-        out[(size_t)layer * P + (size_t)y * N + x] = raw[map_index(N, y, x, layer)];
+  for(int y = 0; y < N; ++y)
+  {
+    for(int x = 0; x < N; ++x)
+    {
+      if constexpr (MAP_COMPACT)
+      {
+        float const *a = raw.data() + map_compact_a(N, y, x) / sizeof(float);
+        float const *b = raw.data() + map_compact_b(N, y, x) / sizeof(float);
+
+        out[(size_t)y * N + x] = make_float4(a[0], a[1], a[2], 0.0f);
+        out[P + (size_t)y * N + x] = make_float4(a[3], b[0], b[1], 0.0f);
+      }
+      else
+      {
+        float4 const *r = reinterpret_cast<float4 const*>(raw.data());
+
+        out[(size_t)y * N + x] = r[map_index(N, y, x, 0)];
+        out[P + (size_t)y * N + x] = r[map_index(N, y, x, 1)];
+      }
+    }
+  }
 
   return DATUM_OCEAN_OK;
 }

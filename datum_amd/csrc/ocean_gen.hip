@@ -63,7 +63,7 @@ namespace ocean
   {
     datum_ocean_set set;
     GenFrame frame;
-    float4 const *map;     // the cascade's displacement map, 2 * N * N float4 (map_index)
+    float4 const *map;     // the cascade's displacement map, map_cascade_bytes(N) bytes (ocean_kernels.hip: map_compact_a / map_index)
     int N;
     int sizex;
     int sizey;
@@ -206,7 +206,8 @@ namespace ocean
     return { a.x * inv, a.y * inv, a.z * inv };
   }
 
-  // sincos_phase (ocean_kernels.hip) of two arguments: the same reduction and polynomials, packed
+  // sincos_phase (ocean_kernels.hip) of two arguments: the same reduction and polynomials, packed.  Always the software form
+  // here: the swell phase reaches 1e5..1e6 at the horizon, far outside v_sin_f32's domain
   __device__ __forceinline__ void sincos_phase2(v2 x, v2 &sn, v2 &cs)
   {
     v2 t = x * 0.636619772367581343f;                            // x * 2/pi
@@ -243,43 +244,87 @@ namespace ocean
     return { (v.x + q[0] * tt.x) + (uy * tt.z - uz * tt.y), (v.y + q[0] * tt.y) + (uz * tt.x - ux * tt.z), (v.z + q[0] * tt.z) + (ux * tt.y - uy * tt.x) };
   }
 
-  // Float4 index of a texel column's / row's part of map_index (ocean_kernels.hip); the two add up to the texel of layer 0.
-  //   PLAIN   N <= 1024: whole rows, groups of 4 x 1 texels          index = y * 2N + (x & ~3) * 2 + (x & 3)
-  //   BANDED  2048: bands of band_cols(N) columns, 4 x 1 groups
-  //   PATCHED 4096: bands, groups of 2 x 2 texels
+  // BYTE offset of a texel column's / row's part of the map layout (ocean_kernels.hip); the two add up to the texel's
+  // displacement: part A of its patch, (dx, dy, dz, nx), in the compact layout -- whose part B, (ny, nz), lies at
+  // A + 256 - bcolumn(i) - brow(j) -- or its float4 of layer 0 in the 32-byte layout (layer 1 is MAP_GROUP float4 on).
+  //   PLAIN   N <= 1024: whole rows
+  //   BANDED  2048 and 4096: bands of band_cols(N) columns
+  //   PATCHED (32-byte layout only) 4096: bands, groups of 2 x 2 texels
   enum GenLayout { GEN_PLAIN = 0, GEN_BANDED = 1, GEN_PATCHED = 2 };
 
   template<int LAYOUT> struct TexelIndex
   {
     int ln, lb, bmask;
+    int lpw, lph;            // compact: log2 of the patch's columns and rows
 
-    __device__ __forceinline__ TexelIndex(int N) : ln(31 - __builtin_clz(N)), lb(31 - __builtin_clz(band_cols(N))), bmask(band_cols(N) - 1) { }
+    __device__ __forceinline__ TexelIndex(int N) : ln(31 - __builtin_clz(N)), lb(31 - __builtin_clz(band_cols(N))), bmask(band_cols(N) - 1),
+                                                   lpw(31 - __builtin_clz(map_patch_cols(N))), lph(31 - __builtin_clz(map_patch_rows(N))) { }
 
     __device__ __forceinline__ int column(int i) const
     {
-      if constexpr (LAYOUT == GEN_PLAIN)
-        return i + (i & ~3);
+      if constexpr (MAP_COMPACT)
+      {
+        int const inband = ((i & bmask) >> lpw) * MAP_PATCH_BYTES + ((i & ((1 << lpw) - 1)) << 4);
+
+        if constexpr (LAYOUT == GEN_PLAIN)
+          return inband;
+        else
+          return (i >> lb) * (3 << (3 + ln + lb)) + inband;           // 24 N B bytes per band
+      }
+      else if constexpr (LAYOUT == GEN_PLAIN)
+        return (i + (i & ~3)) * 16;
       else if constexpr (LAYOUT == GEN_BANDED)
-        return ((i >> lb) << (1 + ln + lb)) + ((i & bmask) & ~3) * 2 + (i & 3);
+        return (((i >> lb) << (1 + ln + lb)) + ((i & bmask) & ~3) * 2 + (i & 3)) * 16;
       else
-        return ((i >> lb) << (1 + ln + lb)) + ((i & bmask) & ~1) * 4 + (i & 1);
+        return (((i >> lb) << (1 + ln + lb)) + ((i & bmask) & ~1) * 4 + (i & 1)) * 16;
     }
 
     __device__ __forceinline__ int row(int j) const
     {
-      if constexpr (LAYOUT == GEN_PATCHED)
-        return ((j >> 1) << (2 + lb)) + ((j & 1) << 1);
+      if constexpr (MAP_COMPACT)
+        return (j >> lph) * (3 << (7 + lb - lpw)) + ((j & ((1 << lph) - 1)) << (4 + lpw));     // 384 B / PW bytes per patch row
+      else if constexpr (LAYOUT == GEN_PATCHED)
+        return (((j >> 1) << (2 + lb)) + ((j & 1) << 1)) * 16;
       else
-        return j << (1 + lb);
+        return (j << (1 + lb)) * 16;
     }
+
+    // compact: 8 * (the texel's index in its patch), column and row part
+    __device__ __forceinline__ int bcolumn(int i) const { return (i & ((1 << lpw) - 1)) << 3; }
+    __device__ __forceinline__ int brow(int j) const { return (j & ((1 << lph) - 1)) << (3 + lpw); }
   };
 
   static_assert(MAP_GROUP == 4, "a group is one 128-byte line: 8 float4");
+
+  // what a corner's second fetch brings: (ny, nz) in the compact layout, the whole normal texel otherwise
+  typedef std::conditional<MAP_COMPACT, float2, float4>::type GenNormalFetch;
 
   //|---------------------- the kernel ------------------------------------------
   // (One function, local arrays: with the three stages as functions over structs, or inside a loop over tiles, hipcc keeps
   // 134-154 registers instead of 86 and spills -- measured 17.7 against 16.3 us; a persistent loop, 3 or 4 workgroups
   // per CU: 17.1 / 18.1 us; a 1024-thread workgroup per CU sampling a 64^2 map from LDS: 24.5 us.  profiles/r03_gen_experiments.txt)
+
+  template<bool COMPACT> struct NormalFetch;
+
+  template<> struct NormalFetch<true>
+  {
+    static __device__ __forceinline__ float2 load(__amdgpu_buffer_rsrc_t rmap, int, int compact_offset) { return buf_load_f32x2(rmap, compact_offset, 0); }
+    static __device__ __forceinline__ float2 ablated() { return make_float2(0.1f, 0.9f); }
+    static __device__ __forceinline__ float x(float4 a, float2) { return a.w; }
+    static __device__ __forceinline__ float y(float4, float2 b) { return b.x; }
+    static __device__ __forceinline__ float z(float4, float2 b) { return b.y; }
+  };
+
+  template<> struct NormalFetch<false>
+  {
+    static __device__ __forceinline__ float4 load(__amdgpu_buffer_rsrc_t rmap, int displacement_offset, int) { return buf_load_f32x4_aux<0>(rmap, displacement_offset + MAP_GROUP * 16, 0); }
+    static __device__ __forceinline__ float4 ablated() { return make_float4(0.0f, 0.1f, 0.9f, 0.0f); }
+    static __device__ __forceinline__ float x(float4, float4 b) { return b.x; }
+    static __device__ __forceinline__ float y(float4, float4 b) { return b.y; }
+    static __device__ __forceinline__ float z(float4, float4 b) { return b.z; }
+  };
+
+  typedef NormalFetch<MAP_COMPACT> GenNormal;
 
 #ifndef OCEAN_GEN_WAVES_PER_SIMD
 #define OCEAN_GEN_WAVES_PER_SIMD 5   // the register budget the kernel is compiled for (96): 101 without it, one wave per SIMD fewer
@@ -334,7 +379,7 @@ namespace ocean
 
     int const nmask = g.N - 1;
 
-    __amdgpu_buffer_rsrc_t const rmap = make_rsrc(g.map, (size_t)2 * g.N * g.N * sizeof(float4));
+    __amdgpu_buffer_rsrc_t const rmap = make_rsrc(g.map, map_cascade_bytes(g.N));
 
     // per phase (PH = 2: two sets of four rows per wave; the second set's ray arithmetic runs under the first set's fetches,
     // the first set's shading under the second set's fetches)
@@ -343,7 +388,8 @@ namespace ocean
     int o00[PH][2], o10[PH][2], o01[PH][2], o11[PH][2];       // byte offsets of the four corners' displacement texels
     bool shaded[PH], near[PH];
     float4 a00[PH][2], a10[PH][2], a01[PH][2], a11[PH][2];      // displacement layer
-    float4 b00[PH][2], b10[PH][2], b01[PH][2], b11[PH][2];      // normal layer
+    GenNormalFetch b00[PH][2], b10[PH][2], b01[PH][2], b11[PH][2];      // normal layer (compact: its y and z; x came with the displacement)
+    int q00[PH][2], q10[PH][2], q01[PH][2], q11[PH][2];       // compact: byte offsets of the four corners' (ny, nz)
 
     #pragma unroll
     for(int ph = 0; ph < PH; ++ph)
@@ -416,8 +462,8 @@ namespace ocean
 
         int const i1 = (i0 + 1) & nmask, j1 = (j0 + 1) & nmask;
 
-        int const c0 = texel.column(i0) * 16, c1 = texel.column(i1) * 16;
-        int const r0 = texel.row(j0) * 16, r1 = texel.row(j1) * 16;
+        int const c0 = texel.column(i0), c1 = texel.column(i1);
+        int const r0 = texel.row(j0), r1 = texel.row(j1);
 
         // A zero weight along an axis (beyond |coordinate| = 2^23 texels: every ray above the horizon): the second texel of
         // that axis is not needed (0 * finite adds nothing).  Its offset is pushed out of the buffer's range: zeros come
@@ -425,6 +471,14 @@ namespace ocean
         bool const wantx = ax[i] != 0.0f, wanty = ay[i] != 0.0f;
 
         o00[ph][i] = r0 + c0; o10[ph][i] = wantx ? r0 + c1 : -256; o01[ph][i] = wanty ? r1 + c0 : -256; o11[ph][i] = (wantx && wanty) ? r1 + c1 : -256;
+
+        if constexpr (MAP_COMPACT)
+        {
+          int const bc0 = texel.bcolumn(i0), bc1 = texel.bcolumn(i1);
+          int const br0 = 256 - texel.brow(j0), br1 = 256 - texel.brow(j1);
+
+          q00[ph][i] = o00[ph][i] + br0 - bc0; q10[ph][i] = wantx ? o10[ph][i] + br0 - bc1 : -256; q01[ph][i] = wanty ? o01[ph][i] + br1 - bc0 : -256; q11[ph][i] = (wantx && wanty) ? o11[ph][i] + br1 - bc1 : -256;
+        }
 
         near[ph] = near[ph] || wantx || wanty;
       }
@@ -440,10 +494,10 @@ namespace ocean
       // eight displacement fetches of 64 lanes later the line may have left the cache again)
 #ifdef OCEAN_GEN_ABLATE_LOADS      // timing-only builds (tools/): no map fetches
       #define OCEAN_GEN_FETCH_A(C) a##C[ph][i] = make_float4(0.01f * (float)(o##C[ph][i] & 7), 0.02f, 0.03f * (float)(o##C[ph][i] & 3), 0.0f)
-      #define OCEAN_GEN_FETCH_B(C) b##C[ph][i] = make_float4(0.0f, 0.1f, 0.9f, 0.0f)
+      #define OCEAN_GEN_FETCH_B(C) b##C[ph][i] = GenNormal::ablated()
 #else
       #define OCEAN_GEN_FETCH_A(C) a##C[ph][i] = buf_load_f32x4_aux<0>(rmap, o##C[ph][i], 0)
-      #define OCEAN_GEN_FETCH_B(C) b##C[ph][i] = buf_load_f32x4_aux<0>(rmap, o##C[ph][i] + MAP_GROUP * 16, 0)
+      #define OCEAN_GEN_FETCH_B(C) b##C[ph][i] = GenNormal::load(rmap, o##C[ph][i], q##C[ph][i])
 #endif
 
       if (shaded[ph])
@@ -509,7 +563,11 @@ namespace ocean
 
       if (shaded[ph])
       {
-        p3 const dn = { OCEAN_GEN_BLEND(b, x), OCEAN_GEN_BLEND(b, y), OCEAN_GEN_BLEND(b, z) };
+        #define OCEAN_GEN_BLENDN(F) pfma(w11[ph], v2{ F(a11[ph][0], b11[ph][0]), F(a11[ph][1], b11[ph][1]) }, pfma(w01[ph], v2{ F(a01[ph][0], b01[ph][0]), F(a01[ph][1], b01[ph][1]) }, pfma(w10[ph], v2{ F(a10[ph][0], b10[ph][0]), F(a10[ph][1], b10[ph][1]) }, w00[ph] * v2{ F(a00[ph][0], b00[ph][0]), F(a00[ph][1], b00[ph][1]) })))
+
+        p3 const dn = { OCEAN_GEN_BLENDN(GenNormal::x), OCEAN_GEN_BLENDN(GenNormal::y), OCEAN_GEN_BLENDN(GenNormal::z) };
+
+        #undef OCEAN_GEN_BLENDN
 
         // tbn[2] = normalize(-normal.xy, 1 - normal.z), tbn[0] = normalize(1 - tangent.x, -tangent.y, tangent.z), tbn[1] = tbn[0] x tbn[2]
         p3 const t2 = normalize3(p3{ -f.nx * ct[ph], -f.ny * ct[ph], pfma(-f.nz, st[ph], 1.0f) });
@@ -588,7 +646,7 @@ namespace ocean
 
   inline GenLayout gen_layout(int N)
   {
-    return (map_group_rows(N) == 2) ? GEN_PATCHED : (band_cols(N) != N) ? GEN_BANDED : GEN_PLAIN;
+    return (!MAP_COMPACT && map_group_rows(N) == 2) ? GEN_PATCHED : (band_cols(N) != N) ? GEN_BANDED : GEN_PLAIN;
   }
 
   // everything but the set header, the map and the vertex buffer
@@ -600,7 +658,7 @@ namespace ocean
     g.sizey = sizey;
     g.tilesx = (sizex + GEN_TILE_X - 1) / GEN_TILE_X;
     g.tiles = g.tilesx * ((sizey + GEN_TILE_Y - 1) / GEN_TILE_Y);
-    g.chunk = ((size_t)2 * N * N * sizeof(float4) > ((size_t)4 << 20)) ? OCEAN_GEN_XCD_CHUNK * g.tilesx : 0;
+    g.chunk = (map_cascade_bytes(N) > ((size_t)4 << 20)) ? OCEAN_GEN_XCD_CHUNK * g.tilesx : 0;
   }
 
   inline hipError_t launch_gen(GenArgs &g, hipStream_t stream)

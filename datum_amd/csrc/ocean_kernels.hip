@@ -154,6 +154,57 @@ namespace ocean
   // float4 per row of a band: from a texel to the same column map_group_rows(N) * k rows on it is k * map_group_rows(N) * map_row_pitch(N)
   __host__ __device__ __forceinline__ constexpr int map_row_pitch(int N) { return 2 * band_cols(N); }
 
+  // COMPACT layout (round 4, OCEAN_MAP_COMPACT): 24 bytes per texel instead of 32 -- the two RGBA32F layers' .w channels are
+  // constant zero (map.comp:79-80) and nothing reads them (gen.comp:113-114 takes .xyz), yet they were a quarter of what the
+  // write-bound column pass stores.  Per cascade, bands as above; inside a band PATCHES of PW x PH = 16 texels, patch rows
+  // one after the other; a patch is 384 bytes = three 128-byte lines:
+  //     part A, 256 bytes: texel j = (y % PH) * PW + x % PW  ->  float4 (dx, dy, dz, nx)   at 16 j
+  //     part B, 128 bytes: texel j                            ->  float2 (ny, nz)           at 256 + 8 j
+  // PW = the column pass's tile width at that resolution (8 up to 256^2, 4 up to 2048^2, 2 at 4096^2), so that the 16 texels of
+  // a patch are 16 neighbouring lanes of a column-pass wave: one 16-byte and one 8-byte store instruction per thread and slot
+  // write two whole lines and one whole line per patch -- no lane trades, no partial lines.  For ocean.gen a 4 x 4 patch holds
+  // the four corners of a bilinear fetch more often than a 4 x 1 group did.
+#ifndef OCEAN_MAP_COMPACT
+#define OCEAN_MAP_COMPACT 1
+#endif
+  constexpr bool MAP_COMPACT = OCEAN_MAP_COMPACT != 0;
+
+  constexpr int MAP_PATCH = 16;                   // texels per patch
+  constexpr int MAP_PATCH_BYTES = 384;
+
+  __host__ __device__ __forceinline__ constexpr int map_patch_cols(int N) { return N <= 256 ? 8 : (N <= 2048 ? 4 : 2); }     // == ColCfg<N>::W (asserted there)
+  __host__ __device__ __forceinline__ constexpr int map_patch_rows(int N) { return MAP_PATCH / map_patch_cols(N); }
+
+  // bytes of one cascade's maps
+  __host__ __device__ __forceinline__ constexpr size_t map_cascade_bytes(int N) { return (size_t)N * N * (MAP_COMPACT ? 24 : 32); }
+
+  // byte offset of texel (x, y)'s part A inside its cascade's block; part B is map_compact_b(...)
+  __host__ __device__ __forceinline__ constexpr size_t map_compact_patch(int N, int y, int x)
+  {
+    int const B = band_cols(N);
+    int const PW = map_patch_cols(N), PH = map_patch_rows(N);
+
+    return (size_t)(x / B) * 24 * N * B + ((size_t)(y / PH) * (B / PW) + (x % B) / PW) * MAP_PATCH_BYTES;
+  }
+
+  __host__ __device__ __forceinline__ constexpr int map_compact_j(int N, int y, int x) { return (y % map_patch_rows(N)) * map_patch_cols(N) + x % map_patch_cols(N); }
+
+  __host__ __device__ __forceinline__ constexpr size_t map_compact_a(int N, int y, int x) { return map_compact_patch(N, y, x) + 16 * map_compact_j(N, y, x); }
+  __host__ __device__ __forceinline__ constexpr size_t map_compact_b(int N, int y, int x) { return map_compact_patch(N, y, x) + 256 + 8 * map_compact_j(N, y, x); }
+
+  // bytes from a texel's patch to the patch of the same column k * PH rows on
+  __host__ __device__ __forceinline__ constexpr int map_compact_patchrow_bytes(int N) { return (band_cols(N) / map_patch_cols(N)) * MAP_PATCH_BYTES; }
+
+  // (dx, dy, dz) of a texel whatever the layout (pack kernel)
+  template<bool COMPACT = MAP_COMPACT>
+  __host__ __device__ __forceinline__ float4 map_displacement(float4 const *maps, int N, int y, int x)
+  {
+    if constexpr (COMPACT)
+      return *reinterpret_cast<float4 const*>(reinterpret_cast<char const*>(maps) + map_compact_a(N, y, x));
+    else
+      return maps[map_index(N, y, x, 0)];
+  }
+
   //|---------------------- buffer addressing ----------------------------------
   // Global accesses whose addresses differ between a thread's slots only by a wave-uniform amount go through
   // buffer instructions: one 32-bit VGPR offset per thread plus an SGPR offset per access, instead of a 64-bit
@@ -384,6 +435,102 @@ namespace ocean
 
     return make_float2(kx * inv, ky * inv);
   }
+
+  //|---------------------- two slots per instruction (round 4) ----------------
+  // The row pass's prologue -- update_ocean, sin / cos of the phase, k and 1 / |k| -- works on one float per grid point, and
+  // gfx950's packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) do two per lane per issue: a thread's
+  // slots are taken in pairs (s, s + 1).  With -ffp-contract=off every product and sum is rounded as the scalar form rounds
+  // it (the phase state stays bit-identical to update_ocean's).  A real factor that belongs to ONE slot of a pair enters
+  // the complex operations through the half-select modifiers (broadcast of one half), not through a splat.
+#ifndef OCEAN_ROW_PACKED
+#define OCEAN_ROW_PACKED 1
+#endif
+#ifndef OCEAN_ROW_HW_SINCOS
+#define OCEAN_ROW_HW_SINCOS 0        // v_sin_f32 / v_cos_f32 of phase / 2 pi instead of the reduction + polynomials (accuracy: tools/dbg/hwsin.hip)
+#endif
+
+  typedef float f2_ __attribute__((ext_vector_type(2)));
+
+  __device__ __forceinline__ f2_ pfma2(f2_ a, f2_ b, f2_ c) { return __builtin_elementwise_fma(a, b, c); }
+
+  // sincos_phase of two arguments: the same reduction and polynomials, packed (ocean.gen uses it for the swell phase too)
+  __device__ __forceinline__ void sincos_phase_pair(f2_ x, f2_ &sn, f2_ &cs)
+  {
+#if OCEAN_ROW_HW_SINCOS
+    f2_ const rev = x * 0.15915494309189535f;
+
+    sn = f2_{ __builtin_amdgcn_sinf(rev.x), __builtin_amdgcn_sinf(rev.y) };
+    cs = f2_{ __builtin_amdgcn_cosf(rev.x), __builtin_amdgcn_cosf(rev.y) };
+#else
+    f2_ const t = x * 0.636619772367581343f;                            // x * 2/pi
+    f2_ const k = { __builtin_rintf(t.x), __builtin_rintf(t.y) };
+
+    f2_ r = pfma2(k, f2_{ -1.57079637050628662109375f, -1.57079637050628662109375f }, x);       // pi/2 head
+    r = pfma2(k, f2_{ 4.37113900018624283e-8f, 4.37113900018624283e-8f }, r);                    // pi/2 tail
+
+    f2_ const z = r * r;
+
+    f2_ const sp = pfma2(pfma2(pfma2(f2_{ -1.9515295891e-4f, -1.9515295891e-4f }, z, f2_{ 8.3321608736e-3f, 8.3321608736e-3f }), z, f2_{ -1.6666654611e-1f, -1.6666654611e-1f }), z * r, r);
+    f2_ const cp = pfma2(pfma2(pfma2(f2_{ 2.443315711809948e-5f, 2.443315711809948e-5f }, z, f2_{ -1.388731625493765e-3f, -1.388731625493765e-3f }), z, f2_{ 4.166664568298827e-2f, 4.166664568298827e-2f }), z * z, pfma2(z, f2_{ -0.5f, -0.5f }, f2_{ 1.0f, 1.0f }));
+
+    #pragma unroll
+    for(int i = 0; i < 2; ++i)
+    {
+      int const q = (int)k[i];
+
+      float const s_ = (q & 1) ? cp[i] : sp[i];
+      float const c_ = (q & 1) ? sp[i] : cp[i];
+
+      sn[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s_) ^ (((unsigned)q << 30) & 0x80000000u));
+      cs[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c_) ^ (((unsigned)(q + 1) << 30) & 0x80000000u));
+    }
+#endif
+  }
+
+#if defined(__HIP_DEVICE_COMPILE__) && OCEAN_ASM_COMPLEX
+  // a + c[H] * b
+  template<int H> __device__ __forceinline__ cf fma_real_h(cf a, cf b, f2_ c)
+  {
+    v2f_ va = __builtin_bit_cast(v2f_, a), vb = __builtin_bit_cast(v2f_, b), r;
+
+    if (H == 0)
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(vb), "v"(c), "v"(va));
+    else
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(vb), "v"(c), "v"(va));
+
+    return __builtin_bit_cast(cf, r);
+  }
+
+  // a + c[H] * (-i b) = (a.x + c b.y, a.y - c b.x)
+  template<int H> __device__ __forceinline__ cf fma_negi_h(cf a, cf b, f2_ c)
+  {
+    v2f_ va = __builtin_bit_cast(v2f_, a), vb = __builtin_bit_cast(v2f_, b), r;
+
+    if (H == 0)
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(vb), "v"(c), "v"(va));
+    else
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(vb), "v"(c), "v"(va));
+
+    return __builtin_bit_cast(cf, r);
+  }
+
+  // c[H] * a
+  template<int H> __device__ __forceinline__ cf scale_real_h(cf a, f2_ c)
+  {
+    v2f_ va = __builtin_bit_cast(v2f_, a), r;
+
+    if (H == 0)
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(va), "v"(c));
+    else
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(va), "v"(c));
+
+    return __builtin_bit_cast(cf, r);
+  }
+#else
+  template<int H> __host__ __device__ __forceinline__ cf fma_real_h(cf a, cf b, f2_ c) { return fma_real(a, b, c[H]); }
+  template<int H> __host__ __device__ __forceinline__ cf fma_negi_h(cf a, cf b, f2_ c) { return fma_negi(a, b, c[H]); }
+  template<int H> __host__ __device__ __forceinline__ cf scale_real_h(cf a, f2_ c) { return scale_real(a, c[H]); }
+#endif
 
   // timing-only ablations (never defined in a shipped build): -DOCEAN_ABLATE_ROWLOAD / ROWSTORE / ROWFFT /
   // COLLOAD / COLSTORE / COLFFT remove one ingredient while keeping the rest alive
@@ -839,9 +986,25 @@ namespace ocean
         {
           float const dt = a.dt[k];
 
+#if OCEAN_ROW_PACKED
+          // two slots per instruction: w = omega dt, a = phase + w, b = a - 2 pi (same roundings as advance_phase_fast), then the select
+          f2_ const dt2 = { dt, dt };
+
+          #pragma unroll
+          for(int s = 0; s < E; s += 2)
+          {
+            f2_ const w = f2_{ in.om[s], in.om[s + 1] } * dt2;
+            f2_ const sum = f2_{ ph[s], ph[s + 1] } + w;
+            f2_ const wrapped = sum - f2_{ 6.2831855f, 6.2831855f };
+
+            ph[s] = (sum.x >= 6.2831855f) ? wrapped.x : sum.x;
+            ph[s + 1] = (sum.y >= 6.2831855f) ? wrapped.y : sum.y;
+          }
+#else
           #pragma unroll
           for(int s = 0; s < E; ++s)
             ph[s] = advance_phase_fast(ph[s], in.om[s] * dt);
+#endif
         }
 
         #pragma unroll
@@ -857,6 +1020,25 @@ namespace ocean
       // ocean.sim once per point; the value goes to the thread that holds the negated index
       cf h[E];
 
+#if OCEAN_ROW_PACKED
+      #pragma unroll
+      for(int s = 0; s < E; s += 2)
+      {
+        f2_ sn, cs;
+        sincos_phase_pair(f2_{ ph[s], ph[s + 1] }, sn, cs);
+
+        #pragma unroll
+        for(int i = 0; i < 2; ++i)
+        {
+          // sim_height_products with e^{i phase} from the pair
+          cf const e = cf{ cs[i], sn[i] };
+
+          h[s + i] = add_conj(cmul(cf{ hk[s + i].x, hk[s + i].y }, e), cmul(cf{ hm[s + i].x, hm[s + i].y }, e));
+
+          swap_out[padidx<C::PS>(t + T * (s + i))] = h[s + i];
+        }
+      }
+#else
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
@@ -864,6 +1046,7 @@ namespace ocean
 
         swap_out[padidx<C::PS>(t + T * s)] = h[s];
       }
+#endif
 
       // element 0 once more at index N: the partner of x is N - x for every x, without a wrap
       if (t == 0)
@@ -881,6 +1064,46 @@ namespace ocean
 
       cf v[2][E];
 
+#if OCEAN_ROW_PACKED
+      // k of sim.comp:52 for two slots at a time: (float)x - N/2 is an exact integer, so xf0 + T s equals it bit for bit, and the
+      // products keep wavevector()'s order; 1 / |k| by the bare reciprocal square root of max(k^2, smallest normal) -- at the one
+      // point with k = 0 both components of k are 0 and k^ comes out 0 as sim.comp:54's guard has it
+      float const xf0 = (float)t - 0.5f * (float)N;
+      f2_ const ky2 = { ky * ky, ky * ky };
+      f2_ const kyp = { ky, ky };
+
+      #pragma unroll
+      for(int s = 0; s < E; s += 2)
+      {
+        f2_ const xf = { xf0 + (float)(T * s), xf0 + (float)(T * (s + 1)) };
+        f2_ const kx = (f2_{ 6.2831855f, 6.2831855f } * xf) * f2_{ cc.scale, cc.scale };
+        f2_ const k2 = kx * kx + ky2;
+        f2_ const kinv = { __builtin_amdgcn_rsqf(__builtin_fmaxf(k2.x, 1.17549435e-38f)), __builtin_amdgcn_rsqf(__builtin_fmaxf(k2.y, 1.17549435e-38f)) };
+        f2_ const khx = kx * kinv, khy = kyp * kinv;
+        f2_ const s2 = { 2.0f * slot_sine<E>(ca, s), 2.0f * slot_sine<E>(ca, s + 1) };       // 2 sin(2 pi x / N)
+
+        #pragma unroll
+        for(int i = 0; i < 2; ++i)
+        {
+          cf const n = swap_in[padidx<C::PS>(N - t) - (s + i) * (T + (T >> C::PS))];
+
+          cf const hh = add_conj(h[s + i], n);                                // h~[k] + conj(h~[-k])
+          cf const hhx = (s + i == 0) ? fma_conj(hh, n, cx) : hh;
+          cf const hhy = fma_conj(hh, n, cy);
+
+          if (i == 0)
+          {
+            v[0][s + i] = fma_real_h<0>(hh, hhx, khx);
+            v[1][s + i] = fma_negi_h<0>(scale_real_h<0>(hh, s2), hhy, khy);
+          }
+          else
+          {
+            v[0][s + i] = fma_real_h<1>(hh, hhx, khx);
+            v[1][s + i] = fma_negi_h<1>(scale_real_h<1>(hh, s2), hhy, khy);
+          }
+        }
+      }
+#else
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
@@ -904,6 +1127,7 @@ namespace ocean
         v[0][s] = fma_real(hh, hhx, khx);
         v[1][s] = fma_negi(scale_real(hh, s2), hhy, khy);
       }
+#endif
 
       // every thread has fetched its partner values before pass 0 overwrites the lines
       __syncthreads();
@@ -1029,6 +1253,7 @@ namespace ocean
     static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
 
     static_assert(N % W == 0 && 8 % W == 0, "a tile must sit inside one 8-column block");
+    static_assert(!MAP_COMPACT || (W == map_patch_cols(N) && T % map_patch_rows(N) == 0), "a patch of the compact map layout is 16 neighbouring lanes of a column-pass wave");
     static_assert(OFF_MAIN % 16 == 0, "LDS carve must stay 16-byte aligned");
   };
 
@@ -1235,7 +1460,7 @@ namespace ocean
 
       CascadeConst const cc = a.casc[cascade];
 
-      __amdgpu_buffer_rsrc_t rmaps = make_rsrc(a.maps + (size_t)cascade * 2 * plane, 2 * plane * sizeof(float4));
+      __amdgpu_buffer_rsrc_t rmaps = make_rsrc(reinterpret_cast<char const*>(a.maps) + (size_t)cascade * map_cascade_bytes(N), map_cascade_bytes(N));
 
       // (-1)^(x+y) of map.comp:60; a thread's rows differ by even amounts
       // times the 1/2 of the Hermitian parts, which the row pass leaves out
@@ -1255,12 +1480,18 @@ namespace ocean
 
       float const nz = cc.nz;
 
-      int const o0 = (int)map_index(N, t, x, 0) * 16;   // byte offset of this thread's first texel (layer 0; layer 1 is 16 MAP_GROUP bytes on)
+      int const o0 = MAP_COMPACT ? 0 : (int)map_index(N, t, x, 0) * 16;   // byte offset of this thread's first texel (layer 0; layer 1 is 16 MAP_GROUP bytes on)
 
       // line stores (four-column tiles): this lane's 16 bytes of row (t & ~1) and of row (t | 1): the even quad writes
       // the displacement half of either line, the odd quad the normal half
-      int const olo = (int)map_index(N, t & ~1, x, t & 1) * 16;
-      int const ohi = (int)map_index(N, t | 1, x, t & 1) * 16;
+      int const olo = MAP_COMPACT ? 0 : (int)map_index(N, t & ~1, x, t & 1) * 16;
+      int const ohi = MAP_COMPACT ? 0 : (int)map_index(N, t | 1, x, t & 1) * 16;
+
+      // compact layout: this thread's texel of its patch, part A and part B; slot to slot T / PH patch rows on
+      int const oa = MAP_COMPACT ? (int)map_compact_a(N, t, x) : 0;
+      int const ob = MAP_COMPACT ? (int)map_compact_b(N, t, x) : 0;
+
+      constexpr int SLOTBYTES = (T / map_patch_rows(N)) * map_compact_patchrow_bytes(N);
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
@@ -1290,7 +1521,13 @@ namespace ocean
 #ifndef OCEAN_COL_LINE_STORES
 #define OCEAN_COL_LINE_STORES 1
 #endif
-          if constexpr (OCEAN_COL_LINE_STORES && W == 4 && MAP_GROUP == 4 && map_group_rows(N) == 1)
+          if constexpr (MAP_COMPACT)
+          {
+            // 16 neighbouring lanes = one patch: 256 contiguous bytes (two lines) by the first instruction, 128 (one line) by the second
+            buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, nx * inv), rmaps, oa, SLOTBYTES * s);
+            buf_store_cf_aux<MAPAUX>(cf{ ny * inv, nz * inv }, rmaps, ob, SLOTBYTES * s);
+          }
+          else if constexpr (OCEAN_COL_LINE_STORES && W == 4 && MAP_GROUP == 4 && map_group_rows(N) == 1)
           {
             // Lanes 4 k .. 4 k + 3 of a wave hold the four texels of row t, the next four lanes those of row t + 1.  The
             // two rows trade halves (DPP row shifts by four lanes), so that ONE store instruction writes a row's whole
@@ -1410,7 +1647,6 @@ namespace ocean
   template<bool HALF>
   __global__ void __launch_bounds__(256) ocean_pack_kernel(float4 const *maps, int N, int cascades, void *payload)
   {
-    static_assert(MAP_GROUP == 4 || MAP_GROUP == 1, "the pack kernel reads four neighbouring texels of layer 0");
 
     size_t const groups = (size_t)cascades * N * (N / 4);
 
@@ -1419,14 +1655,14 @@ namespace ocean
       size_t const row = g / (N / 4);                 // cascade * N + y
       int const x0 = (int)(g % (N / 4)) * 4;
 
-      float4 const *src = maps + (row / N) * 2 * N * N;      // the cascade's map block
+      float4 const *src = reinterpret_cast<float4 const*>(reinterpret_cast<char const*>(maps) + (row / N) * map_cascade_bytes(N));      // the cascade's map block
       int const y = (int)(row % N);
 
       float4 t[4];
 
       #pragma unroll
       for(int k = 0; k < 4; ++k)
-        t[k] = src[map_index(N, y, x0 + k, 0)];
+        t[k] = map_displacement(src, N, y, x0 + k);
 
       if constexpr (HALF)
       {

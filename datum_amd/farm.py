@@ -8,7 +8,7 @@ field", is ONE all_gather_into_tensor per batch of steps.  What is gathered (the
   * payload: every rank packs its tiles' displacement into a flat buffer (datum_ocean_pack_displacement,
     include/datum_ocean_hip.h): "xyz32" = (dx, dy, dz) as floats, 12 B per point, exact -- the displacement FIELD
     north_star names; "xyz16" = the same as halves, 8 B per point; "maps" = both map layers as they lie in memory,
-    32 B per point.  xGMI is point to point (7 links x ~153 GB/s per GPU): at 8 ranks a 1024^2 x 4 block is 0.35 GB
+    24 B per point (capi.map_layout).  xGMI is point to point (7 links x ~153 GB/s per GPU): at 8 ranks a 1024^2 x 4 block is 0.35 GB
     received per rank as xyz32 against 0.94 GB as maps.
   * overlap: the payload is double-buffered and the collective of batch k runs on a second stream while the kernels
     of batch k + 1 run on the compute stream (TileGather below); event-ordered, no host synchronisation.
@@ -25,7 +25,7 @@ CASCADE_WAVESCALES = (22.0, 64.0, 176.0, 512.0)
 
 # payload formats: name -> (code of include/datum_ocean_hip.h, torch dtype, elements per grid point)
 PAYLOADS = {
-    "maps": (0, torch.float32, 8),
+    "maps": (0, torch.float32, None),      # per point: texel_bytes / 4 of the module's map layout (capi.map_layout: 6, or 8 in a 32-byte build)
     "xyz32": (1, torch.float32, 3),
     "xyz16": (2, torch.float16, 4),
 }
@@ -50,7 +50,12 @@ def map_block_numel(N, grids):
 
 
 def payload_numel(N, grids, fmt):
-    return grids * N * N * PAYLOADS[fmt][2]
+    per = PAYLOADS[fmt][2]
+    if per is None:
+        from . import capi
+
+        per = capi.map_layout(N)[3] // 4
+    return grids * N * N * per
 
 
 def payload_bytes(N, grids, fmt):

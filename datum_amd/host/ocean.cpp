@@ -165,12 +165,18 @@ namespace
     }
   }
 
-  // park the state that is resident on the context's device (h0 + phase, device to device) under its ids.
-  // `keep`: a slot that must survive (the one about to be resumed): never the eviction victim
-  void park_bound_state(OceanContext &context, OceanContext::Parked const *keep = nullptr)
+  // Park the state that is resident on the context's device (h0 + phase, device to device) under its ids.
+  // `resume`: the slot about to be resumed (or null).  Where the state goes, in this order:
+  //   1. its own slot, if it has one (an older copy of itself)
+  //   2. with a resume slot: the context's SPARE buffer, which then trades places with the resume slot's buffer -- the slot
+  //      being vacated becomes this state's slot, nobody is evicted (N states alternate on N - 1 slots + the spare)
+  //   3. a new slot while there are fewer than MaxParkedStates
+  //   4. the least recently used slot (its state goes back to its host copy + recorded history)
+  // Returns true when case 2 applies: the caller swaps the buffers once it has resumed from the slot.
+  bool park_bound_state(OceanContext &context, OceanContext::Parked *resume = nullptr)
   {
     if (context.boundstate == 0)
-      return;
+      return false;
 
     size_t const bytes = datum_ocean_state_bytes(context.resolution);
 
@@ -180,6 +186,16 @@ namespace
       if (p.stateid == context.boundstate)
         slot = &p;
 
+    if (!slot && resume)
+    {
+      if (!context.spare)
+        check(context.hip, datum_ocean_device_alloc(context.hip, bytes, &context.spare), "datum_ocean_device_alloc");
+
+      check(context.hip, datum_ocean_park_state(context.hip, 0, context.spare, bytes, &context.spareflags), "datum_ocean_park_state");
+
+      return true;
+    }
+
     if (!slot && context.parked.size() < OceanContext::MaxParkedStates)
     {
       void *device = nullptr;
@@ -187,7 +203,7 @@ namespace
       // (allocated before the entry exists: a failed allocation leaves no half-made slot behind)
       check(context.hip, datum_ocean_device_alloc(context.hip, bytes, &device), "datum_ocean_device_alloc");
 
-      context.parked.emplace_back();        // (may move the vector: `keep` is not looked at again on this path)
+      context.parked.emplace_back();
       context.parked.back().device = device;
 
       slot = &context.parked.back();
@@ -195,14 +211,10 @@ namespace
 
     if (!slot)
     {
-      // least recently used, the slot about to be resumed excepted
-      for(auto &p : context.parked)
-        if (&p != keep && (!slot || p.lastuse < slot->lastuse))
+      for(auto &p : context.parked)      // least recently used
+        if (!slot || p.lastuse < slot->lastuse)
           slot = &p;
     }
-
-    if (!slot)
-      return;      // (MaxParkedStates == 1 and that one is being resumed: the bound state goes back to its host copy + history)
 
     check(context.hip, datum_ocean_park_state(context.hip, 0, slot->device, bytes, &slot->flags), "datum_ocean_park_state");
 
@@ -211,6 +223,8 @@ namespace
     slot->appliedupdates = context.appliedupdates;
     slot->appliedlineage = context.appliedlineage;
     slot->lastuse = ++context.useclock;
+
+    return false;
   }
 
   // make the device hold this params' state: h0 (and phase when the whole state was replaced), then every update_ocean
@@ -229,34 +243,43 @@ namespace
 
     if (!continues(context.boundstate, context.appliedupdates, context.appliedlineage))
     {
-      // the slot to resume is looked up FIRST and kept out of the eviction: with more states than slots rendered round-robin the
-      // least recently used slot is exactly the state that comes next.  With the bound state parked into the slot being
-      // resumed they are swapped through the module's own buffers instead (park copies out after resume copied in would
-      // lose one of them), so: resume target found -> park the bound state elsewhere -> resume.
-      size_t resume = context.parked.size();
+      // The slot to resume is looked up FIRST: with more states than slots rendered round-robin the least recently used slot
+      // is exactly the state that comes next, and the slot it vacates is where the bound state should go (park_bound_state).
+      OceanContext::Parked *slot = nullptr;
 
-      for(size_t i = 0; i < context.parked.size(); ++i)
-        if (continues(context.parked[i].stateid, context.parked[i].appliedupdates, context.parked[i].appliedlineage))
-          resume = i;
+      for(auto &p : context.parked)
+        if (continues(p.stateid, p.appliedupdates, p.appliedlineage))
+          slot = &p;
 
-      if (context.boundstate != params.stateid)
-      {
-        park_bound_state(context, resume < context.parked.size() ? &context.parked[resume] : nullptr);
-      }
-
-      OceanContext::Parked *slot = resume < context.parked.size() ? &context.parked[resume] : nullptr;
+      // (with a resume slot park_bound_state never appends to the vector: `slot` stays valid)
+      bool const trade = (context.boundstate != params.stateid) ? park_bound_state(context, slot) : false;
 
       if (slot)
       {
         // rendered here before: the parked phase is ahead of (or level with) params.phase
         check(context.hip, datum_ocean_resume_state(context.hip, 0, slot->device, datum_ocean_state_bytes(context.resolution), slot->flags), "datum_ocean_resume_state");
 
-        context.boundstate = params.stateid;
-        context.boundheight = slot->heightid;
-        context.appliedupdates = slot->appliedupdates;
-        context.appliedlineage = slot->appliedlineage;
+        OceanContext::Parked const resumed = *slot;
+
+        if (trade)
+        {
+          // the vacated slot takes the spare buffer with the state that was bound; its old buffer is the new spare
+          slot->device = context.spare;
+          slot->flags = context.spareflags;
+          slot->stateid = context.boundstate;
+          slot->heightid = context.boundheight;
+          slot->appliedupdates = context.appliedupdates;
+          slot->appliedlineage = context.appliedlineage;
+
+          context.spare = resumed.device;
+        }
 
         slot->lastuse = ++context.useclock;
+
+        context.boundstate = params.stateid;
+        context.boundheight = resumed.heightid;
+        context.appliedupdates = resumed.appliedupdates;
+        context.appliedlineage = resumed.appliedlineage;
       }
       else
       {
@@ -394,6 +417,9 @@ OceanContext::~OceanContext()
     for(auto &p : parked)
       datum_ocean_device_free(hip, p.device);
 
+    if (spare)
+      datum_ocean_device_free(hip, spare);
+
     datum_ocean_destroy(hip);
   }
 }
@@ -418,6 +444,14 @@ size_t release_parked_states(OceanContext &context, OceanParams const *keep)
     freed += datum_ocean_state_bytes(context.resolution);
 
     context.parked.erase(context.parked.begin() + i);
+  }
+
+  if (context.spare && context.hip)
+  {
+    datum_ocean_device_free(context.hip, context.spare);
+    context.spare = nullptr;
+
+    freed += datum_ocean_state_bytes(context.resolution);
   }
 
   return freed;

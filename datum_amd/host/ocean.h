@@ -157,16 +157,20 @@ struct OceanContext
     int flags = 0;
   };
 
-  // Capacity and footprint: up to MaxParkedStates parked copies of datum_ocean_state_bytes(resolution) = 12 N^2 bytes each
-  // (64^2: 48 KB; 1024^2: 12.6 MB; 4096^2: 201 MB, i.e. up to 805 MB of HBM per context), allocated on first use, reused least
-  // recently used first (the slot about to be resumed is never the victim) and held until release_parked_states() or the
-  // context's destruction -- a slot whose OceanParams was re-seeded or destroyed is not noticed by the context.  A context that
-  // alternates between MORE than MaxParkedStates + 1 states falls back to the host copy + recorded history for the evicted ones
-  // (OceanParams::hostphase, or a fetch_ocean_state at least every MaxRecordedUpdates / 2 steps, keeps that possible).
+  // Capacity and footprint: up to MaxParkedStates parked copies + one spare buffer of datum_ocean_state_bytes(resolution) =
+  // 12 N^2 bytes each (64^2: 48 KB; 1024^2: 12.6 MB; 4096^2: 201 MB, i.e. up to 1 GB of HBM per context), allocated on first
+  // use and held until release_parked_states() or the context's destruction -- a slot whose OceanParams was re-seeded or
+  // destroyed is not noticed by the context.  The bound state and the slot being resumed trade places through the spare, so
+  // MaxParkedStates + 1 states alternate without an eviction; with MORE, the least recently used slot is given up and its state
+  // falls back to the host copy + recorded history (OceanParams::hostphase, or a fetch_ocean_state at least every
+  // MaxRecordedUpdates / 2 steps, keeps that possible).
   static const std::size_t MaxParkedStates = 4;
 
   std::vector<Parked> parked;
   std::uint64_t useclock = 0;
+
+  void *spare = nullptr;                  // one more buffer of the same size: the bound state and the slot being resumed trade places through it
+  int spareflags = 0;
 
   OceanContext() = default;
   OceanContext(OceanContext const &) = delete;

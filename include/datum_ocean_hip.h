@@ -82,19 +82,20 @@ int datum_ocean_destroy(datum_ocean_t ctx);
  * use_own != 0: back to the handle's own stream.  Drains the stream in use before switching. */
 int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream, int use_own);
 
-/* Let the displacement maps be written into caller-owned DEVICE memory of
- * cascades * 2 * N * N * 4 floats (e.g. a buffer that is later all-gathered); NULL restores the
- * handle's own buffer.
+/* Let the displacement maps be written into caller-owned DEVICE memory of cascades * N * N * texel_bytes bytes (e.g. a buffer
+ * that is later all-gathered); NULL restores the handle's own buffer.
  * DEVICE LAYOUT of a cascade's map block (the reference's displacementmap is a VK_IMAGE_TILING_OPTIMAL image,
- * ocean.cpp:706, whose physical layout is the driver's; its only reader is ocean.gen): bands of B columns (B = N
- * except for the largest grids); inside a band groups of GX x GY texels (4 x 1: four neighbours of a row; 2 x 2 at
- * 4096: a patch of two rows), group rows one after the other; a group is one 128-byte line: 16 floats of layer 0
- * (its texels row by row: dx, dy, dz, 0) followed by 16 floats of layer 1 (the same texels: nx, ny, nz, 0).
- * float4 index of texel (x, y, layer)
- *   = (x / B) * 2 N B + ((y / GY) * (B / GX) + (x % B) / GX) * 8 + layer * 4 + (y % GY) * GX + x % GX,
- * with (GX, GY, B) from datum_ocean_map_layout.  datum_ocean_read_maps returns the logical image [layer][y][x][4]. */
+ * ocean.cpp:706, whose physical layout is the driver's; its only reader is ocean.gen's sampler, ocean.cpp:759): 24 bytes per
+ * texel -- the .w channels of the two RGBA32F layers are constant zero (map.comp:79-80) and are not stored.  Bands of B
+ * columns (B = N except for the largest grids); inside a band PATCHES of PW x PH = 16 texels, patch rows one after the other;
+ * a patch is 384 bytes = three 128-byte lines: 16 x float4 (dx, dy, dz, nx), then 16 x float2 (ny, nz), texel
+ * j = (y % PH) * PW + x % PW of the patch at 16 j and 256 + 8 j.
+ *   byte offset of texel (x, y)'s patch = (x / B) * 24 N B + ((y / PH) * (B / PW) + (x % B) / PW) * 384
+ * with (PW, PH, B, texel_bytes) from datum_ocean_map_layout (texel_bytes = 24; a build with -DOCEAN_MAP_COMPACT=0 keeps round
+ * 3's 32-byte layout: groups of GX x GY texels, one 128-byte line each, 16 floats of layer 0 then 16 floats of layer 1).
+ * datum_ocean_read_maps returns the reference's logical image [layer][y][x][4] with .w = 0. */
 int datum_ocean_bind_maps(datum_ocean_t ctx, void *device_ptr, size_t bytes);
-int datum_ocean_map_layout(int resolution, int *group_cols, int *group_rows, int *band);
+int datum_ocean_map_layout(int resolution, int *group_cols, int *group_rows, int *band, int *texel_bytes);
 int datum_ocean_maps_device(datum_ocean_t ctx, void **device_ptr, size_t *bytes);
 
 /* -- state (OceanParams arrays, ocean.h:67-72) ------------------------------------------------------- */
@@ -155,7 +156,7 @@ int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, 
  * nothing in the reference: it has one device).  Packs the displacement of every cascade of the handle into
  * caller-owned DEVICE memory, enqueued on the handle's stream behind the last displace, so that the collective can
  * read it on another stream while the next displace overwrites the maps:
- *   MAPS   the whole map block as it lies in memory, both layers (32 B per point, device layout of bind_maps)
+ *   MAPS   the whole map block as it lies in memory, both layers (24 B per point, device layout of bind_maps)
  *   XYZ32  layer 0 only, [cascade][y][x] (dx, dy, dz) as three floats   (12 B per point, exact)
  *   XYZ16  layer 0 only, [cascade][y][x] (dx, dy, dz, 0) as four halves  (8 B per point, round to nearest) */
 #define DATUM_OCEAN_PAYLOAD_MAPS 0

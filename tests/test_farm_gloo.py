@@ -178,7 +178,7 @@ def test_tile_gather_single_rank_passthrough():
         assert float(tg.result()[0]) == float(k)
     assert farm.payload_bytes(64, 2, "xyz32") == 2 * 64 * 64 * 12
     assert farm.payload_bytes(64, 2, "xyz16") == 2 * 64 * 64 * 8
-    assert farm.payload_bytes(64, 2, "maps") == 2 * 64 * 64 * 32
+    assert farm.payload_bytes(64, 2, "maps") == 2 * 64 * 64 * 24
 
 
 def test_single_rank_is_a_view():

@@ -101,26 +101,48 @@ def test_abi_argument_errors_without_gpu():
     assert lib.datum_ocean_destroy(None) == capi.OK
 
 
-@pytest.mark.parametrize("N", [64, 256, 1024, 2048, 4096])
+@pytest.mark.parametrize("N", [64, 256, 512, 1024, 2048, 4096])
 def test_map_layout_formula_and_view(N):
-    # the documented index formula of include/datum_ocean_hip.h (datum_ocean_bind_maps) against capi.map_layers, no GPU
+    # the documented layout of include/datum_ocean_hip.h (datum_ocean_bind_maps) against capi.map_layers, no GPU
     from datum_amd import capi
 
-    GX, GY, B = capi.map_layout(N)
-    assert GX * GY == 4 and N % B == 0 and B % GX == 0
-    assert (GX, GY) == ((2, 2) if N == 4096 else (4, 1))
-
+    PW, PH, B, TB = capi.map_layout(N)
+    assert N % B == 0 and B % PW == 0
     rs = np.random.RandomState(N)
     ys, xs = rs.randint(0, N, 4096), rs.randint(0, N, 4096)
     ys[:4], xs[:4] = [0, 0, N - 1, N - 1], [0, N - 1, 0, N - 1]
-    raw = np.zeros(2 * N * N, np.int64)                       # one id per float4
-    for layer in (0, 1):
-        idx = (xs // B) * 2 * N * B + ((ys // GY) * (B // GX) + (xs % B) // GX) * 8 + layer * 4 + (ys % GY) * GX + xs % GX
-        raw[idx] = 1 + layer * N * N + ys * N + xs
-    view = capi.map_layers(np.repeat(raw, 4), N)
-    for layer in (0, 1):
-        assert np.array_equal(view[layer, ys, xs, 0], 1 + layer * N * N + ys * N + xs)
-    assert np.count_nonzero(view[..., 0]) == np.count_nonzero(raw)
+    ident = (1 + ys * N + xs).astype(np.float32)                # (exact in fp32 up to 2^24 = 4096^2)
+    if TB == 24:
+        # patches of PW x PH = 16 texels, 384 bytes: 16 x (dx, dy, dz, nx) then 16 x (ny, nz)
+        assert PW * PH == 16 and (PW, PH) == ((8, 2) if N <= 256 else (4, 4) if N <= 2048 else (2, 8))
+        raw = np.zeros(N * N * 6, np.float32)
+        patch = (xs // B) * 24 * N * B + ((ys // PH) * (B // PW) + (xs % B) // PW) * 384
+        j = (ys % PH) * PW + xs % PW
+        a, b = (patch + 16 * j) // 4, (patch + 256 + 8 * j) // 4
+        for k in range(4):
+            raw[a + k] = ident + 0.25 * k if N < 2048 else ident     # component tags only where fp32 still holds them
+        raw[b + 0] = ident
+        raw[b + 1] = ident
+        view = capi.map_layers(raw, N)
+        assert view.shape == (2, N, N, 4) and np.all(view[..., 3] == 0)
+        if N < 2048:
+            assert np.array_equal(view[0, ys, xs, :3], ident[:, None] + np.array([0, 0.25, 0.5], np.float32))
+            assert np.array_equal(view[1, ys, xs, 0], ident + 0.75)
+        else:
+            assert np.array_equal(view[0, ys, xs, 0], ident)
+        assert np.array_equal(view[1, ys, xs, 1], ident) and np.array_equal(view[1, ys, xs, 2], ident)
+        assert np.count_nonzero(view[0, ..., 0]) == len(set(zip(ys.tolist(), xs.tolist())))
+    else:
+        GX, GY = PW, PH
+        assert GX * GY == 4 and (GX, GY) == ((2, 2) if N == 4096 else (4, 1))
+        raw = np.zeros(2 * N * N, np.int64)                       # one id per float4
+        for layer in (0, 1):
+            idx = (xs // B) * 2 * N * B + ((ys // GY) * (B // GX) + (xs % B) // GX) * 8 + layer * 4 + (ys % GY) * GX + xs % GX
+            raw[idx] = 1 + layer * N * N + ys * N + xs
+        view = capi.map_layers(np.repeat(raw, 4), N)
+        for layer in (0, 1):
+            assert np.array_equal(view[layer, ys, xs, 0], 1 + layer * N * N + ys * N + xs)
+        assert np.count_nonzero(view[..., 0]) == np.count_nonzero(raw)
 
 
 def test_reference_weights_match_oracle(oracle):

@@ -627,7 +627,7 @@ def test_error_codes(capi):
         capi.Ocean(96, 1)
 
 
-@pytest.mark.parametrize("N", [256, 2048, 4096])       # 4 x 1 groups, bands, bands of 2 x 2 patches
+@pytest.mark.parametrize("N", [256, 1024, 2048, 4096])       # 8 x 2 and 4 x 4 patches, bands, bands of 2 x 8 patches
 def test_bound_maps_and_caller_stream(capi, oracle, torch, N):
     # maps written straight into a caller-owned device buffer on the caller's stream (the all-gather path)
     p = oracle.EXAMPLE
@@ -645,7 +645,8 @@ def test_bound_maps_and_caller_stream(capi, oracle, torch, N):
         oc.bind_maps(buf.data_ptr(), buf.numel() * 4)
         oc.displace()
         stream.synchronize()
-        assert np.array_equal(capi.map_layers(buf.cpu().numpy(), N), own)     # the device layout interleaves the layers (map_layers)
+        assert np.array_equal(capi.map_layers(buf.cpu().numpy()[:capi.map_block_floats(N)], N), own)     # the device layout is the module's own (map_layers)
+        assert bool((buf[capi.map_block_floats(N):] == 0).all())                                          # and nothing is written behind it
         oc.bind_maps(0, 0)
         oc.set_stream(None)
 
@@ -828,7 +829,7 @@ def test_pack_displacement_payloads(capi, oracle, torch, N, C):
             assert bool((got[-16:] == 7.0).all())          # nothing written past the payload
             if fmt == "maps":
                 for c in range(C):
-                    blk = got[c * 2 * N * N * 4:(c + 1) * 2 * N * N * 4].numpy()
+                    blk = got[c * capi.map_block_floats(N):(c + 1) * capi.map_block_floats(N)].numpy()
                     assert np.array_equal(capi.map_layers(blk, N), want[c])
             else:
                 for c in range(C):

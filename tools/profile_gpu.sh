@@ -6,7 +6,7 @@ out=gpurun_out/$1; shift
 rm -rf $out
 mkdir -p $out
 export TMPDIR=/tmp
-ARGS="--cpu-seconds 0 --no-frame $*"   # bench.py defaults (2000 steps, 100 warm-up, 1024x1024 x 4) without the CPU leg and the 64^2 frame
+ARGS="--cpu-seconds 0 --no-frame --no-regime $*"   # bench.py defaults (2000 steps, 100 warm-up, 1024x1024 x 4) without the CPU leg and the 64^2 frame
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $ARGS > $out/trace.log 2>&1
 i=0
 for pmc in \

@@ -3,7 +3,7 @@
 # usage: tools/sizes.sh [lib.so]    (lib: a variant of the module; default the shipped one)
 [ -n "${1:-}" ] && export DATUM_OCEAN_HIP_LIB=$(realpath $1)
 run() {
-  python bench.py --cpu-seconds 0 "$@" | python -c "
+  python bench.py --cpu-seconds 0 --no-regime "$@" | python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); r=j['roofline']; c=j['config']
 print(f\"{c['resolution']:5d}^2 x {c['cascades_per_gpu']:2d} {'fp16' if 'fp16' in c['workload'] else 'fp32'}  {j['value']:9.0f} grids/s  step {j['ms_per_step']*1e3:8.1f} us  row {r['rowpass']['ms']*1e3:7.1f} us  col {r['colpass']['ms']*1e3:7.1f} us  step_frac {r['step_frac']:.3f}  dominant {r['kernel']} frac {r['frac']:.3f}\")"
