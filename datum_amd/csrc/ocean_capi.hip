@@ -59,6 +59,12 @@ struct datum_ocean_ctx
   std::vector<ImportedMemory> importedmemory;
   std::vector<hipExternalSemaphore_t> importedsemaphores;
 
+  // ocean.gen of a large mesh as two half launches that run at the same time: the second half on a stream of the module's,
+  // forked from and joined to the handle's stream by events (profiles/r04_gen_levers.txt)
+  hipStream_t genstream = nullptr;
+  hipEvent_t genfork = nullptr, genjoin = nullptr;
+  int gensplitrows = 0;               // mesh rows from which the launch is split (0: never)
+
   ocean::Farm *farm = nullptr;        // the tile farm's communicator, stream and double-buffered payload (datum_ocean_farm_init)
 
   // profiling
@@ -334,7 +340,9 @@ namespace
       double const bound = 12.0 * ctx->N * (1.41421356 * (double)m);
       int e = (bound > 0) ? (int)std::floor(std::log2(60000.0 / bound)) : 0;
 
-      e = e > 24 ? 24 : (e < -24 ? -24 : e);
+      // (the exponent follows max |h0| over the whole range in which 2^e and 2^-e are normal floats with room to spare: a
+      // sea 2^-40 times smaller than the example's must not land in half's denormals.  Round 3 clamped at +-24.)
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
 
       ctx->casc[c].specscale = std::ldexp(1.0f, e);
       ctx->casc[c].specinv = std::ldexp(1.0f, -e);
@@ -449,6 +457,12 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
   ctx->N = resolution;
   ctx->cascades = cascades;
 
+#ifndef OCEAN_GEN_SPLIT_ROWS
+#define OCEAN_GEN_SPLIT_ROWS 0
+#endif
+  // (tools: DATUM_OCEAN_GEN_SPLIT_ROWS overrides the build's threshold)
+  ctx->gensplitrows = getenv("DATUM_OCEAN_GEN_SPLIT_ROWS") ? atoi(getenv("DATUM_OCEAN_GEN_SPLIT_ROWS")) : OCEAN_GEN_SPLIT_ROWS;
+
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1)
@@ -535,6 +549,14 @@ int datum_ocean_destroy(datum_ocean_t ctx)
     (void)hipStreamSynchronize(ctx->stream);
 
   farm_teardown(ctx);
+
+  if (ctx->genstream)
+  {
+    (void)hipStreamSynchronize(ctx->genstream);
+    (void)hipStreamDestroy(ctx->genstream);
+    (void)hipEventDestroy(ctx->genfork);
+    (void)hipEventDestroy(ctx->genjoin);
+  }
 
   for(hipEvent_t e : ctx->events)
     (void)hipEventDestroy(e);
@@ -977,7 +999,29 @@ int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, 
   g.vertices = (float*)vertices_device;
   gen_shape(g, ctx->N, sizex, sizey);
 
-  HIPCHECK(ctx, launch_gen(g, ctx->stream));
+  int const groups = gen_groups(g);
+
+  if (ctx->gensplitrows > 0 && sizey >= ctx->gensplitrows && groups >= 64)
+  {
+    if (!ctx->genstream)
+    {
+      HIPCHECK(ctx, hipStreamCreateWithFlags(&ctx->genstream, hipStreamNonBlocking));
+      HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->genfork, hipEventDisableTiming));
+      HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->genjoin, hipEventDisableTiming));
+    }
+
+    // (halves in whole sets of eight workgroups: workgroup b of a launch runs on XCD b % 8, which the chunk order relies on)
+    int const first = ((groups / 2 + 7) / 8) * 8;
+
+    HIPCHECK(ctx, hipEventRecord(ctx->genfork, ctx->stream));
+    HIPCHECK(ctx, hipStreamWaitEvent(ctx->genstream, ctx->genfork, 0));
+    HIPCHECK(ctx, launch_gen_part(g, first, groups - first, ctx->genstream));
+    HIPCHECK(ctx, hipEventRecord(ctx->genjoin, ctx->genstream));
+    HIPCHECK(ctx, launch_gen_part(g, 0, first, ctx->stream));
+    HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->genjoin, 0));
+  }
+  else
+    HIPCHECK(ctx, launch_gen(g, ctx->stream));
 
   return DATUM_OCEAN_OK;
 }

@@ -70,6 +70,7 @@ namespace ocean
     int tilesx;
     int tiles;
     int chunk;             // tiles per XCD chunk, 0: tiles in launch order
+    int block0;            // index of this launch's first workgroup in the whole mesh's list (a mesh may be launched in two parts)
     float *vertices;
 #ifdef OCEAN_STAMPS
     unsigned long long *stamps;   // diagnostic builds only (tools/dbg/genstamps.hip): [workgroup][16] timestamps
@@ -304,6 +305,34 @@ namespace ocean
   // 134-154 registers instead of 86 and spills -- measured 17.7 against 16.3 us; a persistent loop, 3 or 4 workgroups
   // per CU: 17.1 / 18.1 us; a 1024-thread workgroup per CU sampling a 64^2 map from LDS: 24.5 us.  profiles/r03_gen_experiments.txt)
 
+  // cache policy of the vertex stream's stores (50 MB per 1024 x 1024 mesh, written once, read by the graphics queue):
+  // 0 plain, 1 sc0, 2 nt, 16 sc1, 17 sc0 sc1 (written through), 18 sc1 nt ...  measured: profiles/r04_gen_levers.txt
+#ifndef OCEAN_GEN_STORE_AUX
+#define OCEAN_GEN_STORE_AUX 0
+#endif
+
+  __device__ __forceinline__ void store_vertex_float4(float4 *at, float4 v)
+  {
+    typedef float f4_ __attribute__((ext_vector_type(4)));
+
+    f4_ const d = { v.x, v.y, v.z, v.w };
+
+    if constexpr (OCEAN_GEN_STORE_AUX == 0)
+      *at = v;
+    else if constexpr (OCEAN_GEN_STORE_AUX == 1)
+      asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(at), "v"(d) : "memory");
+    else if constexpr (OCEAN_GEN_STORE_AUX == 2)
+      asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(at), "v"(d) : "memory");
+    else if constexpr (OCEAN_GEN_STORE_AUX == 16)
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(at), "v"(d) : "memory");
+    else if constexpr (OCEAN_GEN_STORE_AUX == 17)
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(at), "v"(d) : "memory");
+    else if constexpr (OCEAN_GEN_STORE_AUX == 18)
+      asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(at), "v"(d) : "memory");
+    else
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(at), "v"(d) : "memory");
+  }
+
   template<bool COMPACT> struct NormalFetch;
 
   template<> struct NormalFetch<true>
@@ -354,7 +383,7 @@ namespace ocean
     // dealt to the XCDs in turn: neighbouring tiles share an L2 (1024^2 maps: 36.4 -> 31.0 us), and every XCD gets its
     // share of the cheap rows above the horizon (one contiguous run of tiles per XCD: 43 us).  Small maps sit in every
     // L2 anyway; there the launch order is kept (64^2 maps: 16.5 against 17.1 us).
-    int tile = (int)blockIdx.x;
+    int tile = (int)blockIdx.x + g.block0;
 
     if (g.chunk)
     {
@@ -628,7 +657,7 @@ namespace ocean
         if (mine[j].w == 123456.789f)
 #endif
         if (c < rowlen && y0 + r < g.sizey)
-          out[(unsigned)(r * g.sizex * 3 + c)] = mine[j];
+          store_vertex_float4(out + (unsigned)(r * g.sizex * 3 + c), mine[j]);
       }
 
       if (PH > 1)
@@ -659,25 +688,41 @@ namespace ocean
     g.tilesx = (sizex + GEN_TILE_X - 1) / GEN_TILE_X;
     g.tiles = g.tilesx * ((sizey + GEN_TILE_Y - 1) / GEN_TILE_Y);
     g.chunk = (map_cascade_bytes(N) > ((size_t)4 << 20)) ? OCEAN_GEN_XCD_CHUNK * g.tilesx : 0;
+    g.block0 = 0;
   }
 
-  inline hipError_t launch_gen(GenArgs &g, hipStream_t stream)
+  inline void const *gen_kernel_for(int N)
+  {
+    switch(gen_layout(N))
+    {
+      case GEN_PLAIN: return reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_PLAIN>);
+      case GEN_BANDED: return reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_BANDED>);
+      default: return reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_PATCHED>);
+    }
+  }
+
+  // workgroups of the whole mesh (with XCD chunks: rounded up to whole sets of eight chunks)
+  inline int gen_groups(GenArgs const &g)
+  {
+    return g.chunk ? ((g.tiles + 8 * g.chunk - 1) / (8 * g.chunk)) * 8 * g.chunk : g.tiles;
+  }
+
+  // workgroups [first, first + count) of the mesh's list on `stream`
+  inline hipError_t launch_gen_part(GenArgs &g, int first, int count, hipStream_t stream)
   {
     void *args[] = { &g };
-    void const *kernel = nullptr;
-
-    switch(gen_layout(g.N))
-    {
-      case GEN_PLAIN: kernel = reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_PLAIN>); break;
-      case GEN_BANDED: kernel = reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_BANDED>); break;
-      case GEN_PATCHED: kernel = reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_PATCHED>); break;
-    }
+    void const *kernel = gen_kernel_for(g.N);
 
     if (GEN_LDS > 64 * 1024)       // (tools/ builds only)
       (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEN_LDS);
 
-    int const groups = g.chunk ? ((g.tiles + 8 * g.chunk - 1) / (8 * g.chunk)) * 8 * g.chunk : g.tiles;
+    g.block0 = first;
 
-    return hipLaunchKernel(kernel, dim3(groups), dim3(GEN_THREADS), args, GEN_LDS, stream);
+    return hipLaunchKernel(kernel, dim3(count), dim3(GEN_THREADS), args, GEN_LDS, stream);
+  }
+
+  inline hipError_t launch_gen(GenArgs &g, hipStream_t stream)
+  {
+    return launch_gen_part(g, 0, gen_groups(g), stream);
   }
 }

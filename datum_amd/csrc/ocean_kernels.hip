@@ -392,6 +392,11 @@ namespace ocean
     *cos_out = ((q + 1) & 2) ? -c : c;
   }
 
+  // The row pass's sin / cos of ONE phase: the hardware's v_sin_f32 / v_cos_f32 of phase / 2 pi (OCEAN_ROW_HW_SINCOS; what a
+  // Vulkan driver makes of the shader's sin() and cos(), sim.comp:61-62, on this GPU: |error| <= 4.8e-7 for phases in [0, 2 pi),
+  // tools/dbg/hwsin.hip) or sincos_phase above
+  __device__ __forceinline__ void sincos_row(float x, float *sin_out, float *cos_out);
+
   // one point of data/ocean.sim.comp:52-66: h~ from h0(k), h0 at the mirror index and the phase, evaluated as
   // h0(k) e^{i phase} + conj(h0(mirror) e^{i phase})  (two complex products and a conjugating add: 5 packed
   // instructions; equal to the shader's expanded form, sim.comp:65-66, up to rounding)
@@ -446,7 +451,7 @@ namespace ocean
 #define OCEAN_ROW_PACKED 1
 #endif
 #ifndef OCEAN_ROW_HW_SINCOS
-#define OCEAN_ROW_HW_SINCOS 0        // v_sin_f32 / v_cos_f32 of phase / 2 pi instead of the reduction + polynomials (accuracy: tools/dbg/hwsin.hip)
+#define OCEAN_ROW_HW_SINCOS 1        // v_sin_f32 / v_cos_f32 of phase / 2 pi instead of the reduction + polynomials (accuracy: tools/dbg/hwsin.hip)
 #endif
 
   typedef float f2_ __attribute__((ext_vector_type(2)));
@@ -461,6 +466,12 @@ namespace ocean
 
     sn = f2_{ __builtin_amdgcn_sinf(rev.x), __builtin_amdgcn_sinf(rev.y) };
     cs = f2_{ __builtin_amdgcn_cosf(rev.x), __builtin_amdgcn_cosf(rev.y) };
+
+    // gfx940+: a VALU instruction that reads the result of a transcendental one needs two wait states in between.  hipcc
+    // inserts them for the instructions it emits, but the consumers here are the inline-asm packed complex products, which
+    // its hazard recognizer does not look into (measured: RMSE 1e-3..6e-2 at the resolutions where the scheduler happened to
+    // put a product right behind a v_cos_f32).  The results pass through this statement, so every reader comes after it.
+    asm volatile("s_nop 1" : "+v"(sn), "+v"(cs));
 #else
     f2_ const t = x * 0.636619772367581343f;                            // x * 2/pi
     f2_ const k = { __builtin_rintf(t.x), __builtin_rintf(t.y) };
@@ -484,6 +495,22 @@ namespace ocean
       sn[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s_) ^ (((unsigned)q << 30) & 0x80000000u));
       cs[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c_) ^ (((unsigned)(q + 1) << 30) & 0x80000000u));
     }
+#endif
+  }
+
+  __device__ __forceinline__ void sincos_row(float x, float *sin_out, float *cos_out)
+  {
+#if OCEAN_ROW_HW_SINCOS
+    float const rev = x * 0.15915494309189535f;
+
+    float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+
+    asm volatile("s_nop 1" : "+v"(sn), "+v"(cs));       // (see sincos_phase_pair)
+
+    *sin_out = sn;
+    *cos_out = cs;
+#else
+    sincos_phase(x, sin_out, cos_out);
 #endif
   }
 
@@ -706,7 +733,10 @@ namespace ocean
   template<int N, bool H16 = false>
   struct RowCfg
   {
-    static constexpr int E = (N >= OCEAN_ROW_E16_FROM) ? 16 : default_radix(N);
+#ifndef OCEAN_ROW_E4_UPTO
+#define OCEAN_ROW_E4_UPTO 64         // row pass: 4 points per thread up to this resolution (twice the threads per row pair; small grids are latency-bound)
+#endif
+    static constexpr int E = (N >= OCEAN_ROW_E16_FROM) ? 16 : (N <= OCEAN_ROW_E4_UPTO ? 4 : default_radix(N));
     static constexpr int T = Plan<N, E>::T;
 #ifndef OCEAN_ROW_PAIR_THREADS
 #define OCEAN_ROW_PAIR_THREADS 128   // threads of a row-pass workgroup when one row pair needs fewer (small grids are
@@ -717,6 +747,9 @@ namespace ocean
     // results wait in 16 registers, as floats in 32 and the kernel spills (4096^2 fp32: 155 against 132 us)
     static constexpr bool SEQ = (N >= OCEAN_ROW_SEQ_FROM) && (H16 || OCEAN_ROW_SEQ_FP32);
     static constexpr int K = SEQ ? 1 : 2;                                  // LDS lines per row
+    // the prologue two slots per instruction -- not in the sequential form, whose registers are full (4096^2 fp16: 56 bytes of
+    // spill and 134 us packed against 28 bytes and 124-128 us: profiles/r04_rowpass_packed.txt)
+    static constexpr bool PACKED = (OCEAN_ROW_PACKED != 0) && !SEQ;
     static constexpr int PS = 4;
     static constexpr int LINE = LineFFT<N, PS, E>::LINE + 2;               // + element 0 again at index N (the Hermitian swap), kept 16-byte aligned
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
@@ -986,7 +1019,8 @@ namespace ocean
         {
           float const dt = a.dt[k];
 
-#if OCEAN_ROW_PACKED
+          if constexpr (C::PACKED)
+          {
           // two slots per instruction: w = omega dt, a = phase + w, b = a - 2 pi (same roundings as advance_phase_fast), then the select
           f2_ const dt2 = { dt, dt };
 
@@ -1000,11 +1034,13 @@ namespace ocean
             ph[s] = (sum.x >= 6.2831855f) ? wrapped.x : sum.x;
             ph[s + 1] = (sum.y >= 6.2831855f) ? wrapped.y : sum.y;
           }
-#else
+          }
+          else
+          {
           #pragma unroll
           for(int s = 0; s < E; ++s)
             ph[s] = advance_phase_fast(ph[s], in.om[s] * dt);
-#endif
+          }
         }
 
         #pragma unroll
@@ -1020,7 +1056,8 @@ namespace ocean
       // ocean.sim once per point; the value goes to the thread that holds the negated index
       cf h[E];
 
-#if OCEAN_ROW_PACKED
+      if constexpr (C::PACKED)
+      {
       #pragma unroll
       for(int s = 0; s < E; s += 2)
       {
@@ -1038,15 +1075,22 @@ namespace ocean
           swap_out[padidx<C::PS>(t + T * (s + i))] = h[s + i];
         }
       }
-#else
+      }
+      else
+      {
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
-        h[s] = sim_height_products(hk[s], hm[s], ph[s]);
+        float sn, cs;
+        sincos_row(ph[s], &sn, &cs);
+
+        cf const e = cf{ cs, sn };
+
+        h[s] = add_conj(cmul(cf{ hk[s].x, hk[s].y }, e), cmul(cf{ hm[s].x, hm[s].y }, e));      // sim_height_products
 
         swap_out[padidx<C::PS>(t + T * s)] = h[s];
       }
-#endif
+      }
 
       // element 0 once more at index N: the partner of x is N - x for every x, without a wrap
       if (t == 0)
@@ -1064,7 +1108,8 @@ namespace ocean
 
       cf v[2][E];
 
-#if OCEAN_ROW_PACKED
+      if constexpr (C::PACKED)
+      {
       // k of sim.comp:52 for two slots at a time: (float)x - N/2 is an exact integer, so xf0 + T s equals it bit for bit, and the
       // products keep wavevector()'s order; 1 / |k| by the bare reciprocal square root of max(k^2, smallest normal) -- at the one
       // point with k = 0 both components of k are 0 and k^ comes out 0 as sim.comp:54's guard has it
@@ -1103,7 +1148,9 @@ namespace ocean
           }
         }
       }
-#else
+      }
+      else
+      {
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
@@ -1127,7 +1174,7 @@ namespace ocean
         v[0][s] = fma_real(hh, hhx, khx);
         v[1][s] = fma_negi(scale_real(hh, s2), hhy, khy);
       }
-#endif
+      }
 
       // every thread has fetched its partner values before pass 0 overwrites the lines
       __syncthreads();
@@ -1218,7 +1265,10 @@ namespace ocean
 #ifndef OCEAN_COL_E16_TO
 #define OCEAN_COL_E16_TO 2048
 #endif
-    static constexpr int E = (N >= OCEAN_COL_E16_FROM && N < OCEAN_COL_E16_TO) ? 16 : default_radix(N);
+#ifndef OCEAN_COL_E4_UPTO
+#define OCEAN_COL_E4_UPTO 64
+#endif
+    static constexpr int E = (N >= OCEAN_COL_E16_FROM && N < OCEAN_COL_E16_TO) ? 16 : (N <= OCEAN_COL_E4_UPTO ? 4 : default_radix(N));
     static constexpr int T = Plan<N, E>::T;
 #ifndef OCEAN_COL_THREADS
 #define OCEAN_COL_THREADS 0        // 0 = by size

@@ -45,9 +45,9 @@ def rmse(a, b):
     return float(np.sqrt((d * d).mean()))
 
 
-def make_state(oracle, N, rngseed, wavescale=22.0):
+def make_state(oracle, N, rngseed, wavescale=22.0, waveamplitude=None):
     p = oracle.EXAMPLE
-    _, h0 = oracle.seed(N, rngseed, wavescale, p["waveamplitude"], p["windspeed"], p["winddirection"], sanitize=True)
+    _, h0 = oracle.seed(N, rngseed, wavescale, p["waveamplitude"] if waveamplitude is None else waveamplitude, p["windspeed"], p["winddirection"], sanitize=True)
     return h0
 
 
@@ -768,21 +768,27 @@ def test_flat_ocean(capi, N):
                 assert np.abs(m[1][..., 2] - 1).max() < 1e-6
 
 
+@pytest.mark.parametrize("half", [False, True])
 @pytest.mark.parametrize("case", range(6))
-def test_random_parameters(capi, oracle, case):
-    # three cascades with random wave scales (1 .. 2000), choppiness (0 .. 2), and random runs of 1 .. 12 updates between
-    # displacements (more than 8 pending goes through the phase-only kernel first), some dt negative or large (the
-    # general fmod path): phase bit-exact, maps within 2e-6 of the largest |value| of the oracle's (the 1e-5 absolute
-    # bar belongs to the example parameters; amplitudes here span decades)
+def test_random_parameters(capi, oracle, case, half):
+    # three cascades with random wave scales (1 .. 2000), wave amplitudes over four decades, choppiness (0 .. 2), and random
+    # runs of 1 .. 12 updates between displacements (more than 8 pending goes through the phase-only kernel first), some dt
+    # negative or large (the general fmod path): phase bit-exact, maps within 2e-6 of the largest |value| of the oracle's (the
+    # 1e-5 absolute bar belongs to the example parameters; amplitudes here span decades).
+    # half: the same through the fp16-stored spectrum (set_spectrum_format), whose power-of-two scale has to follow max |h0|
+    # of each cascade: displacement RMSE < 2e-3 of the largest |displacement| (the stated fp16 tolerance), unit normals
+    # within 2e-2, and the phase -- which never passes through the spectrum -- still bit-exact.
     rng = np.random.default_rng(100 + case)
     N = [128, 256, 64, 512, 128, 256][case]
     C = 3
     scales = np.exp(rng.uniform(0.0, np.log(2000.0), C)).astype(np.float32)
     chops = rng.uniform(0.0, 2.0, C).astype(np.float32)
-    states = [make_state(oracle, N, 2000 + 10 * case + c, wavescale=float(scales[c])) for c in range(C)]
+    amps = (0.0025 * 10.0 ** rng.uniform(-2.0, 2.0, C)).astype(np.float32)
+    states = [make_state(oracle, N, 2000 + 10 * case + c, wavescale=float(scales[c]), waveamplitude=float(amps[c])) for c in range(C)]
     phases = [np.zeros((N, N), np.float32) for _ in range(C)]
     w = oracle.weights(N, reduced=True)
     with capi.Ocean(N, C) as oc:
+        oc.set_spectrum_format(half)
         for c in range(C):
             oc.set_cascade(c, float(scales[c]), float(chops[c]))
             oc.upload_state(c, states[c])
@@ -797,10 +803,70 @@ def test_random_parameters(capi, oracle, case):
                 assert np.array_equal(oc.read_state(c), phases[c])
                 ref = oracle.displace(states[c], phases[c].copy(), float(scales[c]), float(chops[c]), w=w)
                 got = oc.read_maps(c)
-                tol = 2e-6 * max(float(np.abs(ref[0]).max()), 1e-12)
-                assert np.abs(got[0][..., :3] - ref[0][..., :3]).max() < 10 * tol
-                assert rmse(got[0][..., :3], ref[0][..., :3]) < tol
-                assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 2e-5
+                assert np.isfinite(got).all()
+                big = max(float(np.abs(ref[0]).max()), 1e-30)
+                if half:
+                    e = rmse(got[0][..., :3], ref[0][..., :3])
+                    assert 1e-8 * big < e < 2e-3 * big, (c, e / big)      # really through halves, and within the stated tolerance
+                    assert np.abs(got[0][..., :3] - ref[0][..., :3]).max() < 2e-2 * big
+                    assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 2e-2
+                else:
+                    tol = 2e-6 * big
+                    assert np.abs(got[0][..., :3] - ref[0][..., :3]).max() < 10 * tol
+                    assert rmse(got[0][..., :3], ref[0][..., :3]) < tol
+                    assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 2e-5
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_power_of_two_amplitudes(capi, oracle, half):
+    # The displacement is linear in h0 and a power of two commutes with every rounding, so h0 * 2^k must give the displacement
+    # * 2^k BIT FOR BIT -- in fp32, and through the fp16-stored spectrum as well, whose scale exponent follows max |h0|
+    # (ocean_capi: size_spectrum_scale; round 3 clamped it to +-24, so that a sea 2^-40 times smaller landed in half's
+    # denormals: the clamp is now +-100).  From 2^-60 (max |h0| ~ 1e-21) to 2^40 (~ 1e9).
+    N = 256
+    p = oracle.EXAMPLE
+    h0 = make_state(oracle, N, 1234)
+    outs = {}
+    with capi.Ocean(N, 1) as oc:
+        oc.set_spectrum_format(half)
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        for k in (0, -60, -30, 20, 40):
+            oc.upload_state(0, np.ldexp(h0, k).astype(np.float32))
+            oc.update(DT)          # (the phase starts from zero again with every upload)
+            oc.displace()
+            outs[k] = oc.read_maps(0)
+    base = outs[0][0][..., :3]
+    assert float(np.abs(base).max()) > 0.1
+    for k in (-60, -30, 20, 40):
+        assert np.array_equal(outs[k][0][..., :3], np.ldexp(base, k).astype(np.float32)), k
+        assert np.isfinite(outs[k]).all()
+
+
+def test_fp16_spectrum_2048(capi, oracle, report):
+    # the fp16-stored spectrum on the banded layout with walking column workgroups (2048^2 had never run with it)
+    N = 2048
+    p = oracle.EXAMPLE
+    h0 = make_state(oracle, N, 1000)
+    with capi.Ocean(N, 1) as oc:
+        oc.set_spectrum_format(True)
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        oc.upload_state(0, h0)
+        for _ in range(2):
+            oc.update(DT)
+            oc.displace()
+        got = oc.read_maps(0)
+        gphase = oc.read_state(0)
+    phase = np.zeros((N, N), np.float32)
+    for _ in range(2):
+        oracle.update(phase, p["wavescale"], DT, mt=True)
+    assert np.array_equal(gphase, phase)
+    ref = oracle.displace(h0, phase.copy(), p["wavescale"], p["choppiness"], w=oracle.weights(N, reduced=True), mt=True)
+    scale = float(np.abs(ref[0][..., :3]).max())
+    e = rmse(got[0][..., :3], ref[0][..., :3])
+    report(f"fp16-stored spectrum N=2048: disp rmse vs oracle {e:.3e} (= {e / scale:.2e} of largest |disp|; bar 2e-3)")
+    assert 1e-7 * scale < e < 2e-3 * scale
+    assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 2e-2
+    assert np.all(got[..., 3] == 0)
 
 
 @pytest.mark.parametrize("N,C", [(64, 2), (256, 3), (2048, 1)])
