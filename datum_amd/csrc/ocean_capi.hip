@@ -1847,9 +1847,9 @@ int datum_ocean_algorithmic_bytes(datum_ocean_t ctx, double *rowpass_bytes, doub
 
   // the ALGORITHM's bytes as the reference states it, three transforms (bench.py's roofline):
   // h0 8 + phase in 4 + phase out 4 + spectrum out 24 | spectrum in 24 + two RGBA32F layers 32.
-  // The packed step moves 16 instead of 24 spectrum bytes each way (32 + 48 = 80 B/pt of HBM traffic).
+  // The packed step moves 16 instead of 24 spectrum bytes each way and 24-byte texels: 32 + 40 = 72 B/pt of HBM traffic.
   // fp16-stored spectrum: 4 + 4 + 4 + 12 | 12 + 32 = 68 B/pt; this build keeps h0 in fp32 and
-  // moves 8 + 4 + 4 + 8 | 8 + 32 = 64 B/pt.
+  // moves 8 + 4 + 4 + 8 | 8 + 24 = 56 B/pt.
   if (rowpass_bytes) *rowpass_bytes = (ctx->half ? 24.0 : 40.0) * pts;
   if (colpass_bytes) *colpass_bytes = (ctx->half ? 44.0 : 56.0) * pts;
 

@@ -9,9 +9,9 @@
 //               reads  h0 (8 B/pt, plus its mirror row through L2), phase (4)   writes phase (4), spectrum (16)
 //   column pass ocean.ffty (data/ocean.ffty.comp:49-100) + ocean.map (data/ocean.map.comp:51-82),
 //               one workgroup per tile of W columns, one column per thread group
-//               reads spectrum (16)    writes 2 x RGBA32F (32)
+//               reads spectrum (16)    writes the two map layers without their zero .w channels (24: map_compact_a)
 //
-// = 80 bytes of HBM traffic per grid point; the algorithm as the reference states it (three transforms) has
+// = 72 bytes of HBM traffic per grid point; the algorithm as the reference states it (three transforms) has
 // 96 algorithmic bytes per point (the figure bench.py's roofline uses) and the reference as
 // written moves 196.
 //
@@ -701,7 +701,7 @@ namespace ocean
   // (the second term of D is the transfer function of the central difference of map.comp:72-75, periodic wrap
   // included: the x slope needs no neighbouring columns any more).  So the row pass transforms and writes two
   // fields instead of three, the column pass reads and transforms two instead of three plus a halo, and one
-  // 16-byte value per point (C, D) crosses between them: 80 B/pt of HBM traffic instead of 96.
+  // 16-byte value per point (C, D) crosses between them: 80 B/pt of HBM traffic instead of 96 (72 with the 24-byte texels).
   //
   // The Hermitian part pairs index (y, x) with ((N-y) % N, (N-x) % N) -- not ocean.sim's own mirror (N-1-y, N-1-x)
   // -- so a row-pass workgroup takes rows y and N-y together (rows 0 and N/2 pair with themselves and share a
@@ -733,10 +733,10 @@ namespace ocean
   template<int N, bool H16 = false>
   struct RowCfg
   {
-#ifndef OCEAN_ROW_E4_UPTO
-#define OCEAN_ROW_E4_UPTO 64         // row pass: 4 points per thread up to this resolution (twice the threads per row pair; small grids are latency-bound)
+#ifndef OCEAN_ROW_E4_AT
+#define OCEAN_ROW_E4_AT 0            // experiments: 4 points per thread at this resolution too (twice the threads per row pair; small grids are latency-bound)
 #endif
-    static constexpr int E = (N >= OCEAN_ROW_E16_FROM) ? 16 : (N <= OCEAN_ROW_E4_UPTO ? 4 : default_radix(N));
+    static constexpr int E = (N >= OCEAN_ROW_E16_FROM) ? 16 : (N == OCEAN_ROW_E4_AT ? 4 : default_radix(N));
     static constexpr int T = Plan<N, E>::T;
 #ifndef OCEAN_ROW_PAIR_THREADS
 #define OCEAN_ROW_PAIR_THREADS 128   // threads of a row-pass workgroup when one row pair needs fewer (small grids are
@@ -754,10 +754,14 @@ namespace ocean
     static constexpr int LINE = LineFFT<N, PS, E>::LINE + 2;               // + element 0 again at index N (the Hermitian swap), kept 16-byte aligned
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
     static constexpr bool WALK = (N >= OCEAN_ROW_WALK_FROM) && PAIRS == 1 && !SEQ;       // see ocean_rowpass_kernel
-    static constexpr size_t LDS = ((size_t)LineFFT<N, 4, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)4 * T : 0)) * sizeof(cf);      // + the walking variant's twiddle stash
+    static constexpr int STASH = 1 + LineTwiddles<N, E>::NMIDREG + Plan<N, E>::M;             // per-thread twiddles the walking variant keeps in LDS between pairs
+    static constexpr size_t LDS = ((size_t)LineFFT<N, 4, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)STASH * T : 0)) * sizeof(cf);
 
-    static constexpr int PER_CU = (LDS * 2 <= (size_t)160 * 1024) ? 2 : 1;                     // persistent workgroups per compute unit (walking)
     static constexpr int FIT = (int)(((size_t)160 * 1024) / LDS);                              // workgroups per CU the LDS allows
+#ifndef OCEAN_ROW_WALK_PER_CU
+#define OCEAN_ROW_WALK_PER_CU 2
+#endif
+    static constexpr int PER_CU = (FIT < OCEAN_ROW_WALK_PER_CU) ? (FIT < 1 ? 1 : FIT) : OCEAN_ROW_WALK_PER_CU;   // persistent workgroups per compute unit (walking)
 #ifndef OCEAN_ROW_SEQ_MAX_PER_CU
 #define OCEAN_ROW_SEQ_MAX_PER_CU 4
 #endif
@@ -936,9 +940,7 @@ namespace ocean
 
     constexpr bool WALK = row_walks<N, H16>();
 
-    static_assert(!WALK || 1 + LineTw<N, E>::type::NMIDREG + P::M <= 4, "twiddle stash");
-
-    cf *twstash = midtab + L::MIDTAB + C::PAIRS * 2 * K * C::LINE;       // [4][T], walking only
+    cf *twstash = midtab + L::MIDTAB + C::PAIRS * 2 * K * C::LINE;       // [STASH][T], walking only
 
     if constexpr (WALK)
     {
@@ -1265,10 +1267,10 @@ namespace ocean
 #ifndef OCEAN_COL_E16_TO
 #define OCEAN_COL_E16_TO 2048
 #endif
-#ifndef OCEAN_COL_E4_UPTO
-#define OCEAN_COL_E4_UPTO 64
+#ifndef OCEAN_COL_E4_AT
+#define OCEAN_COL_E4_AT 0
 #endif
-    static constexpr int E = (N >= OCEAN_COL_E16_FROM && N < OCEAN_COL_E16_TO) ? 16 : (N <= OCEAN_COL_E4_UPTO ? 4 : default_radix(N));
+    static constexpr int E = (N >= OCEAN_COL_E16_FROM && N < OCEAN_COL_E16_TO) ? 16 : (N == OCEAN_COL_E4_AT ? 4 : default_radix(N));
     static constexpr int T = Plan<N, E>::T;
 #ifndef OCEAN_COL_THREADS
 #define OCEAN_COL_THREADS 0        // 0 = by size
