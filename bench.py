@@ -578,7 +578,9 @@ def main():
         pts = float(N) * N * C
         texel = capi.map_layout(N)[3]
         moved = ((24.0 if args.spectrum == "fp16" else 32.0) * pts, ((8.0 if args.spectrum == "fp16" else 16.0) + texel) * pts)
-        dom = ("colpass", col_ms, col_b) if col_ms >= row_ms else ("rowpass", row_ms, row_b)
+        # the dominant kernel: the longer of the two; within 3 % of each other (1024^2 x 4 since round 4: 25.2 and 25.7 us) the
+        # column pass, which carries more of the algorithmic bytes, so that the field does not flip from run to run
+        dom = ("colpass", col_ms, col_b) if col_ms >= 0.97 * row_ms else ("rowpass", row_ms, row_b)
         ach = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
         step_ach = (row_b + col_b) / ((row_ms + col_ms) * 1e-3) / 1e9 if row_ms + col_ms > 0 else 0.0
 

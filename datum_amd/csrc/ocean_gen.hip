@@ -311,6 +311,10 @@ namespace ocean
 #define OCEAN_GEN_STORE_AUX 2         // nt: 26.1 -> 25.5 us from 1024^2 maps, nothing lost from 64^2 maps
 #endif
 
+  // (the policies other than nt exist as inline asm only, for the tools' A/B builds.  An asm store needs the wait states of
+  // "VALU write of a VGPR that holds the data of a VMEM store wider than 64 bits" written out -- hipcc's hazard recognizer does not
+  // look into inline asm, and without them 3 in 10 000 floats of a 1024 x 1024 mesh came out as the NEXT store's address
+  // arithmetic: tools/dbg/gen_compare.py.  The nt form is the compiler's own builtin.)
   __device__ __forceinline__ void store_vertex_float4(float4 *at, float4 v)
   {
     typedef float f4_ __attribute__((ext_vector_type(4)));
@@ -319,18 +323,18 @@ namespace ocean
 
     if constexpr (OCEAN_GEN_STORE_AUX == 0)
       *at = v;
-    else if constexpr (OCEAN_GEN_STORE_AUX == 1)
-      asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(at), "v"(d) : "memory");
     else if constexpr (OCEAN_GEN_STORE_AUX == 2)
-      asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(at), "v"(d) : "memory");
+      __builtin_nontemporal_store(d, reinterpret_cast<f4_*>(at));
+    else if constexpr (OCEAN_GEN_STORE_AUX == 1)
+      asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" :: "v"(at), "v"(d) : "memory");
     else if constexpr (OCEAN_GEN_STORE_AUX == 16)
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(at), "v"(d) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(at), "v"(d) : "memory");
     else if constexpr (OCEAN_GEN_STORE_AUX == 17)
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(at), "v"(d) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(at), "v"(d) : "memory");
     else if constexpr (OCEAN_GEN_STORE_AUX == 18)
-      asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(at), "v"(d) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" :: "v"(at), "v"(d) : "memory");
     else
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(at), "v"(d) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" :: "v"(at), "v"(d) : "memory");
   }
 
   template<bool COMPACT> struct NormalFetch;
