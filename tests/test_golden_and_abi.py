@@ -99,6 +99,15 @@ def test_abi_argument_errors_without_gpu():
     assert lib.datum_ocean_create(None, 0, 64, 1) == capi.EINVAL
     assert lib.datum_ocean_displace(None) == capi.EINVAL
     assert lib.datum_ocean_destroy(None) == capi.OK
+    # the farm's entry points without a handle / with a short id
+    buf = (ctypes.c_char * capi.FARM_ID_BYTES)()
+    assert lib.datum_ocean_farm_unique_id(buf, 64) == capi.EINVAL
+    assert lib.datum_ocean_farm_unique_id(None, capi.FARM_ID_BYTES) == capi.EINVAL
+    assert lib.datum_ocean_farm_init(None, buf, capi.FARM_ID_BYTES, 0, 1, capi.PAYLOAD_XYZ32, 2) == capi.EINVAL
+    assert lib.datum_ocean_farm_gather(None, None) == capi.EINVAL
+    assert lib.datum_ocean_farm_query(None, 0) == capi.EINVAL
+    assert lib.datum_ocean_farm_shutdown(None) == capi.EINVAL
+    assert capi.ENOTREADY < 0 and capi.ECOMM < 0             # module codes stay out of the hipError_t range (positive)
 
 
 @pytest.mark.parametrize("N", [64, 256, 512, 1024, 2048, 4096])
