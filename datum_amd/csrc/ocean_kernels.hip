@@ -1225,7 +1225,22 @@ namespace ocean
           buf_store_cf_aux<OCEAN_SPEC_STORE_AUX>(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
         }
         else
+        {
+#ifdef OCEAN_ABLATE_SPLIT_CD    // timing only (the column pass reads garbage): what the row pass would gain from 12 instead of 16 bytes per point
+          // between the passes -- C of every row and D of one row of each pair, each as a dense array of 8-byte values in blocks of
+          // 8 rows x 16 columns (whole 128-byte lines per block row)
+          {
+            int const cidx = (((y >> 3) * (N / 16) + (t >> 4)) << 7) + ((y & 7) << 4) + (t & 15);
+
+            buf_store_cf_aux<OCEAN_SPEC_STORE_AUX>(v[0][s], rspec, cidx * 8, (T / 16) * 128 * s * 8);
+
+            if (half == 0)
+              buf_store_cf_aux<OCEAN_SPEC_STORE_AUX>(v[1][s], rspec, N * N * 8 + cidx * 8, (T / 16) * 128 * s * 8);
+          }
+#else
           buf_store_f32x4_aux<OCEAN_SPEC_STORE_AUX>(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
+#endif
+        }
       }
 
       OCEAN_STAMP(5);
