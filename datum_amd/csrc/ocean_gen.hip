@@ -86,9 +86,12 @@ namespace ocean
 #define OCEAN_GEN_PHASES 1           // sets of four rows per wave (2: software-pipelined, 32 x 32 vertices per workgroup)
 #endif
 
+#ifndef OCEAN_GEN_THREADS
+#define OCEAN_GEN_THREADS 256        // threads per workgroup (tools: 128 ... 1024; a wave owns 32 x 4 vertices whatever the size)
+#endif
   constexpr int GEN_TILE_X = 32;
-  constexpr int GEN_TILE_Y = 16 * OCEAN_GEN_PHASES;
-  constexpr int GEN_THREADS = 256;
+  constexpr int GEN_THREADS = OCEAN_GEN_THREADS;
+  constexpr int GEN_TILE_Y = 4 * OCEAN_GEN_PHASES * (GEN_THREADS / 64);
 #ifndef OCEAN_GEN_EXTRA_LDS
 #define OCEAN_GEN_EXTRA_LDS 0         // tools/: bytes of unused LDS per workgroup (limits the workgroups per CU: 160 KB / (24 KB + extra))
 #endif
