@@ -179,7 +179,8 @@ int datum_ocean_pack_displacement(datum_ocean_t ctx, int format, void *payload_d
  *               behind the pack and behind the slot's last release, ncclAllGather into the slot's gathered buffer.  The
  *               following displace calls overlap the collective.  *slot = which slot.
  *   result      `hip_stream` (or the handle's own stream when on_handle_stream != 0) waits for the slot's collective;
- *               *gathered_device = world x payload_bytes bytes, rank r's payload at r * payload_bytes
+ *               *gathered_device = world x payload_bytes bytes, rank r's payload at r * payload_bytes.  A slot is gathered into
+ *               again `slots` gathers later: take its result (and release it) before that
  *   release     `hip_stream` (or the handle's) has finished reading the gathered buffer up to this point: the slot's next
  *               collective waits for it.  Needed whenever a consumer reads on a stream of its own.
  *   query       DATUM_OCEAN_OK once the slot's collective has finished, DATUM_OCEAN_ENOTREADY before; never blocks
