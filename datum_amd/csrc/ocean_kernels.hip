@@ -172,7 +172,10 @@ namespace ocean
   constexpr int MAP_PATCH = 16;                   // texels per patch
   constexpr int MAP_PATCH_BYTES = 384;
 
-  __host__ __device__ __forceinline__ constexpr int map_patch_cols(int N) { return N <= 256 ? 8 : (N <= 2048 ? 4 : 2); }     // == ColCfg<N>::W (asserted there)
+#ifndef OCEAN_MAP_PATCH_COLS_4096
+#define OCEAN_MAP_PATCH_COLS_4096 2        // (4 with a column pass of 16 points per thread at 4096^2: four-column tiles)
+#endif
+  __host__ __device__ __forceinline__ constexpr int map_patch_cols(int N) { return N <= 256 ? 8 : (N <= 2048 ? 4 : OCEAN_MAP_PATCH_COLS_4096); }     // == ColCfg<N>::W (asserted there)
   __host__ __device__ __forceinline__ constexpr int map_patch_rows(int N) { return MAP_PATCH / map_patch_cols(N); }
 
   // bytes of one cascade's maps

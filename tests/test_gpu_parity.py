@@ -720,6 +720,40 @@ def test_fp16_spectrum_4096(capi, oracle, report):
     assert np.all(got[..., 3] == 0)
 
 
+def test_gen_split_launch_is_the_same_mesh(capi, oracle, torch, monkeypatch):
+    # datum_ocean_gen can launch a large mesh as two halves at the same time, the second on a stream of the module's, forked from
+    # and joined to the handle's stream by events (DATUM_OCEAN_GEN_SPLIT_ROWS at handle creation; off in the shipped build because
+    # the fork + join costs more than the overlap gains: profiles/r04_gen_levers.txt).  The mesh must be bit for bit the one
+    # launch's, with XCD chunks (1024^2 maps) and without (64^2), and work enqueued behind it must see all of it.
+    for N in (64, 1024):
+        p = oracle.EXAMPLE
+        h0 = make_state(oracle, N, 1000)
+        s = oracle.example_oceanset(N, swellphase=0.4)
+        hs = capi.OceanSet.from_buffer_copy(bytes(s))
+        out = []
+        for split in ("0", "512"):
+            monkeypatch.setenv("DATUM_OCEAN_GEN_SPLIT_ROWS", split)
+            verts = torch.zeros(1024 * 1024 * 12, dtype=torch.float32, device="cuda:0")
+            copy = torch.empty_like(verts)
+            stream = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            with capi.Ocean(N, 1) as oc:
+                oc.set_stream(stream.cuda_stream)
+                oc.set_cascade(0, p["wavescale"], p["choppiness"])
+                oc.upload_state(0, h0)
+                oc.update(DT)
+                oc.displace()
+                oc.gen(0, hs, 1024, 1024, verts.data_ptr())
+                with torch.cuda.stream(stream):
+                    copy.copy_(verts)                     # enqueued behind gen on the handle's stream: must see both halves
+                stream.synchronize()
+                oc.set_stream(None)
+            out.append(copy.cpu())
+        monkeypatch.delenv("DATUM_OCEAN_GEN_SPLIT_ROWS")
+        assert bool(torch.isfinite(out[0]).all()) and float(out[0].abs().max()) > 0
+        assert torch.equal(out[0], out[1]), N
+
+
 def test_gen_ragged_mesh(capi, oracle, torch):
     # mesh sizes that are not multiples of the 16 x 16 vertex tiles (nor of a wave's 4 rows): the staged stores must
     # neither drop nor overrun vertices (guard words after the buffer stay untouched)
