@@ -121,6 +121,20 @@ extern "C"
   // the field itself, as C++ code would set it (no validation: update_ocean then throws)
   void datum_host_params_poke_hostphase(void *p, int on) { static_cast<OceanParams*>(p)->hostphase = (on != 0); }
 
+  // the reference's POD (OceanParamsPod, 82000 bytes): 0 / 1 = not current (fetch_ocean_state first) / -1 = not a 64 x 64 params
+  int datum_host_params_to_pod(void *p, void *pod)
+  {
+    try
+    {
+      return to_pod(*static_cast<OceanParams*>(p), *static_cast<OceanParamsPod*>(pod)) ? 0 : 1;
+    }
+    catch(std::exception const &e) { return caught(e); }
+  }
+
+  void *datum_host_params_from_pod(void const *pod) { return new OceanParams(from_pod(*static_cast<OceanParamsPod const*>(pod))); }
+
+  int datum_host_pod_bytes() { return (int)sizeof(OceanParamsPod); }
+
   float *datum_host_params_seed(void *p) { return static_cast<OceanParams*>(p)->seed.data(); }
   float *datum_host_params_height(void *p) { return static_cast<OceanParams*>(p)->height.data(); }
   float *datum_host_params_phase(void *p) { return static_cast<OceanParams*>(p)->phase.data(); }

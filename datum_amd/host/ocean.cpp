@@ -458,6 +458,67 @@ size_t release_parked_states(OceanContext &context, OceanParams const *keep)
 }
 
 
+///////////////////////// to_pod / from_pod /////////////////////////////////
+bool to_pod(OceanParams const &params, OceanParamsPod &pod)
+{
+  if (params.resolution != OceanContext::WaveResolution)
+    throw runtime_error("ocean: OceanParamsPod is the reference's 64 x 64 OceanParams");
+
+  // the host phase must contain every recorded step (fetch_ocean_state, or hostphase)
+  if (params.phaseupdates != params.firstupdate + params.updates.size())
+    return false;
+
+  pod.plane = params.plane;
+  pod.swelllength = params.swelllength;
+  pod.swellamplitude = params.swellamplitude;
+  pod.swellsteepness = params.swellsteepness;
+  pod.swellspeed = params.swellspeed;
+  pod.swelldirection = params.swelldirection;
+  pod.wavescale = params.wavescale;
+  pod.waveamplitude = params.waveamplitude;
+  pod.windspeed = params.windspeed;
+  pod.winddirection = params.winddirection;
+  pod.choppiness = params.choppiness;
+  pod.smoothing = params.smoothing;
+  pod.swellphase = params.swellphase;
+  pod.flow = params.flow;
+
+  memcpy(pod.seed, params.seed.data(), sizeof(pod.seed));
+  memcpy(pod.height, params.height.data(), sizeof(pod.height));
+  memcpy(pod.phase, params.phase.data(), sizeof(pod.phase));
+
+  return true;
+}
+
+OceanParams from_pod(OceanParamsPod const &pod)
+{
+  OceanParams params(OceanContext::WaveResolution);
+
+  params.plane = pod.plane;
+  params.swelllength = pod.swelllength;
+  params.swellamplitude = pod.swellamplitude;
+  params.swellsteepness = pod.swellsteepness;
+  params.swellspeed = pod.swellspeed;
+  params.swelldirection = pod.swelldirection;
+  params.wavescale = pod.wavescale;
+  params.waveamplitude = pod.waveamplitude;
+  params.windspeed = pod.windspeed;
+  params.winddirection = pod.winddirection;
+  params.choppiness = pod.choppiness;
+  params.smoothing = pod.smoothing;
+  params.swellphase = pod.swellphase;
+  params.flow = pod.flow;
+
+  memcpy(params.seed.data(), pod.seed, sizeof(pod.seed));
+  memcpy(params.height.data(), pod.height, sizeof(pod.height));
+  memcpy(params.phase.data(), pod.phase, sizeof(pod.phase));
+
+  params.heightid = g_stateids++;
+
+  return params;
+}
+
+
 ///////////////////////// seed_ocean ////////////////////////////////////////
 void seed_ocean(OceanParams &params)
 {

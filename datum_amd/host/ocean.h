@@ -5,7 +5,8 @@
 // against datum's ocean API (examples/ocean/ocean.cpp:31,46-52,59,135,165,179) compiles against this header
 // with three documented differences:
 //   1. WaveResolution is a run-time value (OceanContext::resolution / OceanParams::resolution, default 64 =
-//      ocean.h:16); the [64][64] state arrays of OceanParams (ocean.h:69-71) are sized by it.
+//      ocean.h:16); the [64][64] state arrays of OceanParams (ocean.h:69-71) are sized by it.  The reference's POD itself
+//      (memcpy / serialise by value) is OceanParamsPod below, with to_pod / from_pod.
 //   2. The Vulkan objects of OceanContext are replaced by one opaque HIP-module handle
 //      (include/datum_ocean_hip.h); VkSemaphore dependencies become hipEvent_t handles (void*).
 //   3. update_ocean's phase loop (ocean.cpp:223-233) runs on the device: update_ocean() queues dt,
@@ -246,6 +247,33 @@ struct OceanParams
 
   explicit OceanParams(int resolution = OceanContext::WaveResolution);
 };
+
+// The reference's OceanParams byte for byte (src/renderer/ocean.h:48-73 with WaveResolution = 64, ocean.h:16): for callers that
+// memcpy, serialise or load an OceanParams by value -- OceanParams above carries run-time sized arrays and device bookkeeping and
+// is not that POD.  to_pod() needs the host phase to be current (fetch_ocean_state, or hostphase):
+// it returns false, and leaves `pod` alone, when update_ocean calls are recorded that `params.phase` does not contain yet.
+struct OceanParamsPod
+{
+  lml::Plane plane;
+
+  float swelllength, swellamplitude, swellsteepness, swellspeed;
+  lml::Vec2 swelldirection;
+
+  float wavescale, waveamplitude, windspeed;
+  lml::Vec2 winddirection;
+  float choppiness, smoothing;
+
+  float swellphase;
+  float seed[OceanContext::WaveResolution][OceanContext::WaveResolution][2];
+  float height[OceanContext::WaveResolution][OceanContext::WaveResolution][2];
+  float phase[OceanContext::WaveResolution][OceanContext::WaveResolution];
+  lml::Vec2 flow;
+};
+
+static_assert(sizeof(OceanParamsPod) == 82000, "OceanParamsPod must be the reference's OceanParams (ocean.h:48-73): 80 bytes of tunables + swellphase, 3 arrays, flow");
+
+bool to_pod(OceanParams const &params, OceanParamsPod &pod);         // resolution must be 64
+OceanParams from_pod(OceanParamsPod const &pod);                      // a fresh state (new state id, empty history) holding the pod's arrays
 
 class Ocean : public Mesh
 {

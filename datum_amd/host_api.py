@@ -69,6 +69,9 @@ def load():
             "datum_host_params_poke_hostphase": (None, [P, I]),
             "datum_host_release_parked_states": (ctypes.c_size_t, [P, P]),
             "datum_host_parked_states": (I, [P]),
+            "datum_host_params_to_pod": (I, [P, P]),
+            "datum_host_params_from_pod": (P, [P]),
+            "datum_host_pod_bytes": (I, []),
             "datum_host_params_seed": (ctypes.POINTER(F), [P]),
             "datum_host_params_height": (ctypes.POINTER(F), [P]),
             "datum_host_params_phase": (ctypes.POINTER(F), [P]),
@@ -119,6 +122,23 @@ class OceanParams:
         c = OceanParams.__new__(OceanParams)
         c.lib, c.N = self.lib, self.N
         c.p = self.lib.datum_host_params_clone(self.p)
+        return c
+
+    def to_pod(self):
+        """The reference's OceanParams byte for byte (OceanParamsPod, 82000 bytes), or None while recorded steps are missing from the host phase."""
+        buf = ctypes.create_string_buffer(self.lib.datum_host_pod_bytes())
+        rc = self.lib.datum_host_params_to_pod(self.p, buf)
+        if rc < 0:
+            raise HostError(self.lib.datum_host_last_error().decode())
+        return bytes(buf) if rc == 0 else None
+
+    @classmethod
+    def from_pod(cls, pod):
+        lib = load()
+        assert len(pod) == lib.datum_host_pod_bytes()
+        c = cls.__new__(cls)
+        c.lib, c.N = lib, 64
+        c.p = lib.datum_host_params_from_pod(ctypes.create_string_buffer(pod, len(pod)))
         return c
 
     def scalars(self):

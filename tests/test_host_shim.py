@@ -191,3 +191,38 @@ def test_hostphase_switched_on_after_the_history_was_trimmed(host):
     q.set_hostphase(True)
     q.update_ocean(dt)
     assert np.any(q.phase != 0)
+
+
+def test_reference_pod_round_trip(host):
+    # OceanParamsPod: the reference's OceanParams byte for byte (src/renderer/ocean.h:48-73 with WaveResolution = 64) for callers
+    # that memcpy / serialise a params by value.  Field offsets as the reference's struct lays them out; a round trip gives a
+    # fresh state with the same tunables, scalars and arrays; with steps recorded that the host phase does not hold, to_pod says so.
+    p = host.OceanParams(64, **host.EXAMPLE_TUNABLES)
+    p.seed_ocean(1000)
+    pod = p.to_pod()
+    assert pod is not None and len(pod) == 82000
+    f = np.frombuffer(pod, np.float32)
+    # plane (0,0,1,0) | swell length, amplitude, steepness, speed, direction | waves scale, amplitude, windspeed, direction, choppiness, smoothing | swellphase
+    assert tuple(f[:4]) == (0, 0, 1, 0)
+    assert f[4] == 40.0 and f[5] == np.float32(0.8) and f[7] == 1.25
+    assert f[10] == 22.0 and f[11] == np.float32(0.0025) and f[12] == np.float32(7.9)
+    assert f[15] == np.float32(1.35) and f[16] == 320.0 and f[17] == 0.0
+    o = 18
+    assert np.array_equal(f[o:o + 8192].reshape(64, 64, 2), p.seed)
+    assert np.array_equal(f[o + 8192:o + 16384].reshape(64, 64, 2), p.height)
+    assert np.all(f[o + 16384:o + 20480] == 0)                       # phase
+    assert tuple(f[o + 20480:]) == (0, 0)                             # flow
+    q = host.OceanParams.from_pod(pod)
+    assert np.array_equal(q.seed, p.seed) and np.array_equal(q.height, p.height) and np.array_equal(q.phase, p.phase)
+    assert bytes(q.scalars())[:ctypes.sizeof(host.Scalars) - 12] == bytes(p.scalars())[:ctypes.sizeof(host.Scalars) - 12]
+    assert q.to_pod() == pod
+    p.update_ocean(np.float32(1 / 60))                                # recorded, not in the host phase: the POD would be stale
+    assert p.to_pod() is None
+    h = host.OceanParams(64, **host.EXAMPLE_TUNABLES)
+    h.seed_ocean(1000)
+    h.set_hostphase(True)
+    h.update_ocean(np.float32(1 / 60))                                # with hostphase the host copy is current after every call
+    pod2 = h.to_pod()
+    assert pod2 is not None and np.any(np.frombuffer(pod2, np.float32)[o + 16384:o + 20480] != 0)
+    with pytest.raises(host.HostError):
+        host.OceanParams(128).to_pod()
