@@ -584,10 +584,7 @@ def main():
         ach = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
         step_ach = (row_b + col_b) / ((row_ms + col_ms) * 1e-3) / 1e9 if row_ms + col_ms > 0 else 0.0
 
-        if N == 64 and col_ms < 1e-4 * max(row_ms, 1e-9):
-            # 64 x 64: the whole step is ONE kernel (ocean_step64_kernel): its time and all of the step's bytes
-            dom = ("step64", row_ms, row_b + col_b)
-        kernel_name = f"ocean_{dom[0]}_kernel<{N}>" if dom[0] != "step64" else "ocean_step64_kernel"
+        kernel_name = f"ocean_{dom[0]}_kernel<{N}>"
         traffic, traffic_source = measured_traffic(kernel_name, f"{N}x{N} x {C} cascades") if args.spectrum == "fp32" else (None, None)
 
         line = {

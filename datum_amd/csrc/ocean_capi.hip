@@ -65,9 +65,6 @@ struct datum_ocean_ctx
   hipEvent_t genfork = nullptr, genjoin = nullptr;
   int gensplitrows = 0;               // mesh rows from which the launch is split (0: never)
 
-  bool step64 = false;                // N == 64: the whole step in one workgroup per cascade (ocean_step64_kernel)
-  bool specstale = false;             // ... which leaves the work spectrum untouched: datum_ocean_debug_rowpass runs the row pass for it
-
   ocean::Farm *farm = nullptr;        // the tile farm's communicator, stream and double-buffered payload (datum_ocean_farm_init)
 
   // profiling
@@ -532,16 +529,6 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
     }
   }
 
-#ifndef OCEAN_STEP64
-#define OCEAN_STEP64 1
-#endif
-  // (tools / tests: DATUM_OCEAN_STEP64=0 keeps the two kernels at 64 x 64 too)
-  if (resolution == Step64::N && (getenv("DATUM_OCEAN_STEP64") ? atoi(getenv("DATUM_OCEAN_STEP64")) != 0 : OCEAN_STEP64 != 0))
-  {
-    CREATECHECK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_step64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Step64::LDS));
-    ctx->step64 = true;
-  }
-
   CREATECHECK(hipStreamSynchronize(ctx->stream));
 
   #undef CREATECHECK
@@ -978,33 +965,11 @@ int datum_ocean_displace(datum_ocean_t ctx)
 
   hipError_t le = hipSuccess;
 
-  if (ctx->step64 && !ctx->half)
-  {
-    // 64 x 64, the reference's own resolution: one launch, one workgroup per cascade, the passes exchange through LDS
-    void *args[] = { &a };
+  DISPATCH_N(ctx->N, le = launch_rowpass<NN>(ctx, a, ev));
+  HIPCHECK(ctx, le);
 
-    le = launch(reinterpret_cast<void const*>(&ocean_step64_kernel), dim3(ctx->cascades), dim3(Step64::THREADS), args, Step64::LDS, ctx->stream, ev);
-    HIPCHECK(ctx, le);
-
-    if (ev)
-    {
-      // (one kernel: the "column pass" of the profile is empty)
-      HIPCHECK(ctx, hipEventRecord(ev[2], ctx->stream));
-      HIPCHECK(ctx, hipEventRecord(ev[3], ctx->stream));
-    }
-
-    ctx->specstale = true;
-  }
-  else
-  {
-    DISPATCH_N(ctx->N, le = launch_rowpass<NN>(ctx, a, ev));
-    HIPCHECK(ctx, le);
-
-    DISPATCH_N(ctx->N, le = launch_colpass<NN>(ctx, a, ev ? ev + 2 : nullptr));
-    HIPCHECK(ctx, le);
-
-    ctx->specstale = false;
-  }
+  DISPATCH_N(ctx->N, le = launch_colpass<NN>(ctx, a, ev ? ev + 2 : nullptr));
+  HIPCHECK(ctx, le);
 
   if (prof)
     ctx->profsteps += 1;
@@ -1807,19 +1772,6 @@ int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *c, float *d
     return rc;
 
   size_t const P = plane(ctx);
-
-  if (ctx->specstale)
-  {
-    // the last displace was the one-workgroup step, which keeps the row phase's results in LDS: the row pass proper, without a
-    // phase advance, writes the spectrum that displace transformed (same functions, same state)
-    StepArgs a = make_args(ctx, 0, nullptr);
-    hipError_t le = hipSuccess;
-
-    DISPATCH_N(ctx->N, le = launch_rowpass<NN>(ctx, a, nullptr));
-    HIPCHECK(ctx, le);
-
-    ctx->specstale = false;
-  }
 
   if (ctx->half)
     hipLaunchKernelGGL(ocean_unpack_kernel<true>, dim3(1024), dim3(256), 0, ctx->stream, static_cast<ch const*>(ctx->spec) + (size_t)cascade * P, ctx->N, ctx->casc[cascade].specinv, ctx->scratch, ctx->scratch + P);

@@ -1661,251 +1661,6 @@ namespace ocean
     }
   }
 
-  //|---------------------- the whole step of a 64 x 64 grid in ONE workgroup ----------
-  // 64 x 64 is the reference's own resolution (WaveResolution, ocean.h:16).  There the two passes are 8 workgroups each and
-  // each kernel is launch latency and little else (2 x ~3 us for 0.4 MB of traffic).  One 1024-thread workgroup per cascade
-  // holds the whole grid: the row phase is the row pass's (same functions, same order of operations: 32 row pairs x 2 rows x 16
-  // threads, 4 points per thread), its results cross to the column phase through LDS instead of through the work spectrum, the
-  // column phase is the column pass's (64 columns x 16 threads).  Same arithmetic as the two kernels, bit for bit
-  // (tests/test_gpu_parity.py::test_one_workgroup_step_at_64); one launch instead of two.
-  struct Step64
-  {
-    static constexpr int N = 64, E = 4, T = 16, PS = 4;
-    static constexpr int THREADS = 1024;
-    typedef LineFFT<N, 4, E> L;
-    static constexpr int LINE = L::LINE + 2;                          // as RowCfg: element 0 again at index N for the Hermitian swap
-    static constexpr int GP = N + 1;                                  // pitch of the exchange planes (odd: the column phase reads down columns)
-    static constexpr size_t LDS = ((size_t)L::MIDTAB + (size_t)N * 2 * LINE + (size_t)2 * N * GP) * sizeof(cf);
-  };
-
-  __global__ void __launch_bounds__(Step64::THREADS) ocean_step64_kernel(StepArgs a)
-  {
-    typedef Step64 C;
-    typedef LineFFT<C::N, 4, C::E> L;
-
-    constexpr int N = C::N, E = C::E, T = C::T, LINE = C::LINE, GP = C::GP;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    cf *midtab = reinterpret_cast<cf*>(smem);
-    cf *lines = midtab + L::MIDTAB;                 // [64 rows or columns][2 fields][LINE]
-    cf *G = lines + N * 2 * LINE;                   // [2 fields][64 rows][GP]: the row phase's results, read down columns
-
-    int const tid = (int)threadIdx.x;
-
-    for(int i = tid; i < L::MIDTAB; i += C::THREADS)
-      midtab[i] = L::midtab_entry(a.tw, i);
-
-    int const cascade = (int)blockIdx.x;
-    size_t const plane = (size_t)N * N;
-
-    CascadeConst const cc = a.casc[cascade];
-
-    //-- row phase: update_ocean + ocean.sim + ocean.fftx of the two packed fields (ocean_rowpass_kernel's one_item) ----------
-
-    {
-      int const pr = tid / (2 * T), half = (tid % (2 * T)) / T, t = tid % T;
-      int const p = pr;
-      int const y = half ? (p == 0 ? N / 2 : N - p) : p;
-      int const otherhalf = (p == 0) ? half : 1 - half;
-
-      float const *phasein = a.phase + cascade * plane;
-      float2 const *h0 = a.h0 + cascade * plane;
-      float const *omega = a.omega + (size_t)cascade * (N / 2 + 1) * (N / 2 + 1);
-
-      float ph[E], om[E];
-      float2 hk[E], hm[E];
-
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-      {
-        int const x = t + T * s;
-
-        ph[s] = phasein[y * N + x];
-        hk[s] = h0[y * N + x];
-        hm[s] = h0[(N - 1 - y) * N + (N - 1 - x)];
-        om[s] = (a.ndt > 0) ? omega[abs(y - N / 2) * (N / 2 + 1) + abs(x - N / 2)] : 0.0f;
-      }
-
-      cf const ca = a.tw[t];
-
-      typename LineTw<N, E>::type w;
-      LineTw<N, E>::load(a.tw, t, w);
-
-      if (a.ndt > 0)
-      {
-        for(int k = 0; k < a.ndt; ++k)
-        {
-          f2_ const dt2 = { a.dt[k], a.dt[k] };
-
-          #pragma unroll
-          for(int s = 0; s < E; s += 2)
-          {
-            f2_ const wdt = f2_{ om[s], om[s + 1] } * dt2;
-            f2_ const sum = f2_{ ph[s], ph[s + 1] } + wdt;
-            f2_ const wrapped = sum - f2_{ 6.2831855f, 6.2831855f };
-
-            ph[s] = (sum.x >= 6.2831855f) ? wrapped.x : sum.x;
-            ph[s + 1] = (sum.y >= 6.2831855f) ? wrapped.y : sum.y;
-          }
-        }
-
-        float *phaseout = a.phase + cascade * plane;
-
-        #pragma unroll
-        for(int s = 0; s < E; ++s)
-          phaseout[y * N + t + T * s] = ph[s];
-      }
-
-      cf *line = lines + (pr * 2 + half) * 2 * LINE;
-      cf *swap_out = line + LINE;
-      cf const *swap_in = lines + (pr * 2 + otherhalf) * 2 * LINE + LINE;
-
-      cf h[E];
-
-      #pragma unroll
-      for(int s = 0; s < E; s += 2)
-      {
-        f2_ sn, cs;
-        sincos_phase_pair(f2_{ ph[s], ph[s + 1] }, sn, cs);
-
-        #pragma unroll
-        for(int i = 0; i < 2; ++i)
-        {
-          cf const e = cf{ cs[i], sn[i] };
-
-          h[s + i] = add_conj(cmul(cf{ hk[s + i].x, hk[s + i].y }, e), cmul(cf{ hm[s + i].x, hm[s + i].y }, e));
-
-          swap_out[padidx<C::PS>(t + T * (s + i))] = h[s + i];
-        }
-      }
-
-      if (t == 0)
-        swap_out[padidx<C::PS>(N)] = h[0];
-
-      __syncthreads();
-
-      float const ky = wavevector(y, N, cc.scale);
-      float const cy = (y == 0) ? -2.0f : 0.0f;
-      float const cx = (t == 0) ? -2.0f : 0.0f;
-
-      cf v[2][E];
-
-      float const xf0 = (float)t - 0.5f * (float)N;
-      f2_ const ky2 = { ky * ky, ky * ky };
-      f2_ const kyp = { ky, ky };
-
-      #pragma unroll
-      for(int s = 0; s < E; s += 2)
-      {
-        f2_ const xf = { xf0 + (float)(T * s), xf0 + (float)(T * (s + 1)) };
-        f2_ const kx = (f2_{ 6.2831855f, 6.2831855f } * xf) * f2_{ cc.scale, cc.scale };
-        f2_ const k2 = kx * kx + ky2;
-        f2_ const kinv = { __builtin_amdgcn_rsqf(__builtin_fmaxf(k2.x, 1.17549435e-38f)), __builtin_amdgcn_rsqf(__builtin_fmaxf(k2.y, 1.17549435e-38f)) };
-        f2_ const khx = kx * kinv, khy = kyp * kinv;
-        f2_ const s2 = { 2.0f * slot_sine<E>(ca, s), 2.0f * slot_sine<E>(ca, s + 1) };
-
-        #pragma unroll
-        for(int i = 0; i < 2; ++i)
-        {
-          cf const n = swap_in[padidx<C::PS>(N - t) - (s + i) * (T + (T >> C::PS))];
-
-          cf const hh = add_conj(h[s + i], n);
-          cf const hhx = (s + i == 0) ? fma_conj(hh, n, cx) : hh;
-          cf const hhy = fma_conj(hh, n, cy);
-
-          if (i == 0)
-          {
-            v[0][s + i] = fma_real_h<0>(hh, hhx, khx);
-            v[1][s + i] = fma_negi_h<0>(scale_real_h<0>(hh, s2), hhy, khy);
-          }
-          else
-          {
-            v[0][s + i] = fma_real_h<1>(hh, hhx, khx);
-            v[1][s + i] = fma_negi_h<1>(scale_real_h<1>(hh, s2), hhy, khy);
-          }
-        }
-      }
-
-      __syncthreads();
-
-      fft_lines<N, 2, C::PS, E>(v, t, line, LINE, midtab, w, true);
-
-      // to the column phase through LDS (the two kernels: through the work spectrum)
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-      {
-        G[(0 * N + y) * GP + t + T * s] = v[0][s];
-        G[(1 * N + y) * GP + t + T * s] = v[1][s];
-      }
-    }
-
-    __syncthreads();
-
-    //-- column phase: ocean.ffty + ocean.map (ocean_colpass_kernel's one_tile) ------------------------------------------------
-
-    {
-      int const x = tid / T, t = tid % T;
-
-      typename LineTw<N, E>::type w;
-      LineTw<N, E>::load(a.tw, t, w);
-
-      cf v[2][E];
-
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-      {
-        v[0][s] = G[(0 * N + t + T * s) * GP + x];
-        v[1][s] = G[(1 * N + t + T * s) * GP + x];
-      }
-
-      // (every thread has read its values: the height exchange below reuses the planes)
-      fft_lines<N, 2, C::PS, E>(v, t, lines + x * 2 * LINE, LINE, midtab, w, true);
-
-      float const sig = (((x + t) & 1) ? -0.5f : 0.5f) * cc.specinv;
-      float const sigchop = sig * cc.choppiness;
-
-      __syncthreads();
-
-      float *own = reinterpret_cast<float*>(G) + x * (N + 1);
-
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-        own[t + T * s] = v[0][s].x * sig;
-
-      __syncthreads();
-
-      float const nz = cc.nz;
-
-      char *maps = reinterpret_cast<char*>(a.maps) + (size_t)cascade * map_cascade_bytes(N);
-
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-      {
-        int const y = t + T * s;
-
-        float const dz = v[0][s].x * sig;
-        float const dx = v[0][s].y * sigchop;
-        float const dy = v[1][s].x * sigchop;
-
-        float const nx = -(v[1][s].y * sig);
-        float const ny = own[(y + 1) & (N - 1)] - own[(y + N - 1) & (N - 1)];
-        float const inv = rsqrtf(nx * nx + ny * ny + nz * nz);
-
-        if constexpr (MAP_COMPACT)
-        {
-          *reinterpret_cast<float4*>(maps + map_compact_a(N, y, x)) = make_float4(dx, dy, dz, nx * inv);
-          *reinterpret_cast<float2*>(maps + map_compact_b(N, y, x)) = make_float2(ny * inv, nz * inv);
-        }
-        else
-        {
-          reinterpret_cast<float4*>(maps)[map_index(N, y, x, 0)] = make_float4(dx, dy, dz, 0.0f);
-          reinterpret_cast<float4*>(maps)[map_index(N, y, x, 1)] = make_float4(nx * inv, ny * inv, nz * inv, 0.0f);
-        }
-      }
-    }
-  }
-
   // blocked packed spectrum -> two row-major complex planes (datum_ocean_debug_rowpass)
   template<bool H16>
   __global__ void ocean_unpack_kernel(void const *spec, int N, float specinv, cf *c, cf *d)

@@ -754,51 +754,6 @@ def test_gen_split_launch_is_the_same_mesh(capi, oracle, torch, monkeypatch):
         assert torch.equal(out[0], out[1]), N
 
 
-def test_one_workgroup_step_at_64(capi, oracle, monkeypatch):
-    # 64 x 64 (the reference's own WaveResolution, ocean.h:16): the whole step in ONE workgroup per cascade, the two passes
-    # exchanging through LDS (ocean_step64_kernel) -- against the two kernels (DATUM_OCEAN_STEP64=0 at handle creation) on the
-    # same states: maps and phase BIT FOR BIT the same (same functions in the same order), for several cascades, single and
-    # multiple pending updates, the general fmod path (negative dt) in between; and against the oracle.
-    N, C = 64, 3
-    p = oracle.EXAMPLE
-    states = [make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c]) for c in range(C)]
-    runs = [[DT], [DT, DT, np.float32(1 / 30)], [np.float32(-1 / 60)], [DT] * 11, [np.float32(0.25)]]
-    results = []
-    for mode in ("1", "0"):
-        monkeypatch.setenv("DATUM_OCEAN_STEP64", mode)
-        with capi.Ocean(N, C) as oc:
-            for c in range(C):
-                oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c], p["choppiness"])
-                oc.upload_state(c, states[c])
-            got = []
-            for run in runs:
-                for dt in run:
-                    oc.update(float(dt))
-                oc.displace()
-                got.append(([oc.read_maps(c) for c in range(C)], [oc.read_state(c) for c in range(C)]))
-            if mode == "1":
-                cd_fused = oc.debug_rowpass(1)            # the spectrum of the last displace, regenerated by the row pass proper
-            else:
-                cd_two = oc.debug_rowpass(1)
-        results.append(got)
-    monkeypatch.delenv("DATUM_OCEAN_STEP64")
-    for k in range(len(runs)):
-        for c in range(C):
-            assert np.array_equal(results[0][k][1][c], results[1][k][1][c]), ("phase", k, c)
-            assert np.array_equal(results[0][k][0][c], results[1][k][0][c]), ("maps", k, c)
-    assert np.array_equal(cd_fused[0], cd_two[0]) and np.array_equal(cd_fused[1], cd_two[1])
-    # and it is the oracle's step
-    w = oracle.weights(N)
-    for c in range(C):
-        phase = np.zeros((N, N), np.float32)
-        for k, run in enumerate(runs):
-            for dt in run:
-                oracle.update(phase, oracle.CASCADE_WAVESCALES[c], dt)
-            assert np.array_equal(results[0][k][1][c], phase), (k, c)
-            ref = oracle.displace(states[c], phase.copy(), oracle.CASCADE_WAVESCALES[c], p["choppiness"], w=w)
-            assert rmse(results[0][k][0][c], ref) < 1e-5 * max(1.0, float(np.abs(ref[0]).max())), (k, c)
-
-
 def test_gen_ragged_mesh(capi, oracle, torch):
     # mesh sizes that are not multiples of the 16 x 16 vertex tiles (nor of a wave's 4 rows): the staged stores must
     # neither drop nor overrun vertices (guard words after the buffer stay untouched)
