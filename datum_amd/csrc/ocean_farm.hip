@@ -40,17 +40,15 @@ namespace ocean
     ncclResult_t (*GetVersion)(int*) = nullptr;
   };
 
-  // one per process; the first farm call opens it
-  inline RcclApi *rccl_api(std::string *why)
+  // one per process; the first farm call opens it (a function-local static: initialised once, also with several handles on
+  // several threads making their first farm call at the same time)
+  struct RcclOpened
   {
-    static RcclApi api;
-    static std::string failure;
-    static bool tried = false;
+    RcclApi api;
+    std::string failure;
 
-    if (!tried)
+    RcclOpened()
     {
-      tried = true;
-
       char const *names[] = { getenv("DATUM_OCEAN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
 
       for(char const *name : names)
@@ -71,7 +69,9 @@ namespace ocean
           break;
         }
 
-        failure += std::string(failure.empty() ? "" : "; ") + dlerror();
+        char const *err = dlerror();
+
+        failure += std::string(failure.empty() ? "" : "; ") + (err ? err : name);
       }
 
       if (api.lib)
@@ -87,16 +87,21 @@ namespace ocean
         #undef OCEAN_RCCL_SYM
       }
     }
+  };
 
-    if (!api.lib)
+  inline RcclApi *rccl_api(std::string *why)
+  {
+    static RcclOpened opened;
+
+    if (!opened.api.lib)
     {
       if (why)
-        *why = failure;
+        *why = opened.failure;
 
       return nullptr;
     }
 
-    return &api;
+    return &opened.api;
   }
 
   struct FarmSlot
