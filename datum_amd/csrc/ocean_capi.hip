@@ -118,6 +118,7 @@ namespace
     a.omega = ctx->omega;
     a.ndt = ndt;
     a.cascades = ctx->cascades;
+
     for(int i = 0; i < MAX_PENDING; ++i)
       a.dt[i] = (i < ndt) ? dt[i] : 0.0f;
     memcpy(a.casc, ctx->casc, sizeof(a.casc));
@@ -129,6 +130,10 @@ namespace
   {
     *what = "hipFuncSetAttribute(ocean_rowpass_kernel, MaxDynamicSharedMemorySize)";
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N, H16>::LDS);
+    if (e != hipSuccess)
+      return e;
+
+    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N, H16>::LDS);
     if (e != hipSuccess)
       return e;
 
@@ -172,8 +177,15 @@ namespace
   {
     typedef RowCfg<N, H16> C;
 
+    // a phase outside [0, 2 pi) in some cascade (uploaded so, or left there by a negative dt): the instantiation whose sin / cos
+    // take any argument
+    bool wild = false;
+
+    for(int c = 0; c < ctx->cascades; ++c)
+      wild = wild || ctx->wildphase[c];
+
     void *args[] = { &a };
-    void const *kernel = reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>);
+    void const *kernel = wild ? reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16, true>) : reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>);
 
     // work items = groups of row pairs x cascades: one workgroup each, or (largest grids) one persistent workgroup per
     // compute unit that walks its share

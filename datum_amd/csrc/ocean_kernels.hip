@@ -398,7 +398,7 @@ namespace ocean
   // The row pass's sin / cos of ONE phase: the hardware's v_sin_f32 / v_cos_f32 of phase / 2 pi (OCEAN_ROW_HW_SINCOS; what a
   // Vulkan driver makes of the shader's sin() and cos(), sim.comp:61-62, on this GPU: |error| <= 4.8e-7 for phases in [0, 2 pi),
   // tools/dbg/hwsin.hip) or sincos_phase above
-  __device__ __forceinline__ void sincos_row(float x, float *sin_out, float *cos_out);
+  template<bool WILD> __device__ __forceinline__ void sincos_row(float x, float *sin_out, float *cos_out);
 
   // one point of data/ocean.sim.comp:52-66: h~ from h0(k), h0 at the mirror index and the phase, evaluated as
   // h0(k) e^{i phase} + conj(h0(mirror) e^{i phase})  (two complex products and a conjugating add: 5 packed
@@ -461,21 +461,9 @@ namespace ocean
 
   __device__ __forceinline__ f2_ pfma2(f2_ a, f2_ b, f2_ c) { return __builtin_elementwise_fma(a, b, c); }
 
-  // sincos_phase of two arguments: the same reduction and polynomials, packed (ocean.gen uses it for the swell phase too)
-  __device__ __forceinline__ void sincos_phase_pair(f2_ x, f2_ &sn, f2_ &cs)
+  // sincos_phase of two arguments: the same reduction and polynomials, packed
+  __device__ __forceinline__ void sincos_phase_pair_poly(f2_ x, f2_ &sn, f2_ &cs)
   {
-#if OCEAN_ROW_HW_SINCOS
-    f2_ const rev = x * 0.15915494309189535f;
-
-    sn = f2_{ __builtin_amdgcn_sinf(rev.x), __builtin_amdgcn_sinf(rev.y) };
-    cs = f2_{ __builtin_amdgcn_cosf(rev.x), __builtin_amdgcn_cosf(rev.y) };
-
-    // gfx940+: a VALU instruction that reads the result of a transcendental one needs two wait states in between.  hipcc
-    // inserts them for the instructions it emits, but the consumers here are the inline-asm packed complex products, which
-    // its hazard recognizer does not look into (measured: RMSE 1e-3..6e-2 at the resolutions where the scheduler happened to
-    // put a product right behind a v_cos_f32).  The results pass through this statement, so every reader comes after it.
-    asm volatile("s_nop 1" : "+v"(sn), "+v"(cs));
-#else
     f2_ const t = x * 0.636619772367581343f;                            // x * 2/pi
     f2_ const k = { __builtin_rintf(t.x), __builtin_rintf(t.y) };
 
@@ -498,12 +486,46 @@ namespace ocean
       sn[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s_) ^ (((unsigned)q << 30) & 0x80000000u));
       cs[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c_) ^ (((unsigned)(q + 1) << 30) & 0x80000000u));
     }
+  }
+
+  // sin / cos of the phases of two slots.  WILD (the row pass's template flag, chosen per launch by the host): a phase may lie
+  // outside [0, 2 pi) -- uploaded so, or left there by a negative dt -- and v_sin_f32 / v_cos_f32 end at 256 turns: the reduction +
+  // polynomials, which take any argument
+  template<bool WILD>
+  __device__ __forceinline__ void sincos_phase_pair(f2_ x, f2_ &sn, f2_ &cs)
+  {
+#if OCEAN_ROW_HW_SINCOS
+    if constexpr (WILD)
+    {
+      sincos_phase_pair_poly(x, sn, cs);
+      return;
+    }
+
+    f2_ const rev = x * 0.15915494309189535f;
+
+    sn = f2_{ __builtin_amdgcn_sinf(rev.x), __builtin_amdgcn_sinf(rev.y) };
+    cs = f2_{ __builtin_amdgcn_cosf(rev.x), __builtin_amdgcn_cosf(rev.y) };
+
+    // gfx940+: a VALU instruction that reads the result of a transcendental one needs two wait states in between.  hipcc
+    // inserts them for the instructions it emits, but the consumers here are the inline-asm packed complex products, which
+    // its hazard recognizer does not look into (measured: RMSE 1e-3..6e-2 at the resolutions where the scheduler happened to
+    // put a product right behind a v_cos_f32).  The results pass through this statement, so every reader comes after it.
+    asm volatile("s_nop 1" : "+v"(sn), "+v"(cs));
+#else
+    sincos_phase_pair_poly(x, sn, cs);
 #endif
   }
 
+  template<bool WILD>
   __device__ __forceinline__ void sincos_row(float x, float *sin_out, float *cos_out)
   {
 #if OCEAN_ROW_HW_SINCOS
+    if constexpr (WILD)
+    {
+      sincos_phase(x, sin_out, cos_out);
+      return;
+    }
+
     float const rev = x * 0.15915494309189535f;
 
     float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
@@ -829,7 +851,9 @@ namespace ocean
   // copy of its index.  (Two rows per thread in 512-thread workgroups: 96 registers of inputs on top of 209 in 256.)
   template<int N, bool H16 = false> constexpr bool row_walks() { return RowCfg<N, H16>::WALK; }
 
-  template<int N, bool H16>
+  // WILD: a phase may lie outside [0, 2 pi) (sincos_phase_pair); its own instantiation rather than a branch in the kernel: the
+  // registers of the second path cost the 4096^2 fp16 form 12 more bytes of spill and 6 us (profiles/r04_rowpass_packed.txt)
+  template<int N, bool H16, bool WILD = false>
   __global__ void __launch_bounds__((RowCfg<N, H16>::THREADS), (RowCfg<N, H16>::MIN_WAVES)) ocean_rowpass_kernel(StepArgs a)
   {
     typedef RowCfg<N, H16> C;
@@ -1067,7 +1091,7 @@ namespace ocean
       for(int s = 0; s < E; s += 2)
       {
         f2_ sn, cs;
-        sincos_phase_pair(f2_{ ph[s], ph[s + 1] }, sn, cs);
+        sincos_phase_pair<WILD>(f2_{ ph[s], ph[s + 1] }, sn, cs);
 
         #pragma unroll
         for(int i = 0; i < 2; ++i)
@@ -1087,7 +1111,7 @@ namespace ocean
       for(int s = 0; s < E; ++s)
       {
         float sn, cs;
-        sincos_row(ph[s], &sn, &cs);
+        sincos_row<WILD>(ph[s], &sn, &cs);
 
         cf const e = cf{ cs, sn };
 

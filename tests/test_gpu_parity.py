@@ -291,6 +291,36 @@ def test_rowpass_pins_product_sim(capi, oracle, N):
         assert np.abs(back - f64).max() <= 4e-6 * np.abs(f64).max()
 
 
+def test_phases_far_outside_the_circle(capi, oracle):
+    # Uploaded phases of hundreds of turns (the reference would never produce them -- update_ocean keeps the phase in [0, 2 pi) --
+    # but OceanParams::phase is a public array): the row pass must not hand them to v_sin_f32 / v_cos_f32, whose domain ends at
+    # 256 turns; the handle knows the uploaded phase is out of range and the kernel takes the reduction + polynomials there.
+    # Displacement within 1e-4 of the largest |displacement| of the oracle's (sinf / cosf of the same fp32 phases; the reduction
+    # by two constants is good to ~1e-7 * turns), and the next update brings the state back into range, bit for bit update_ocean's.
+    N = 256
+    p = oracle.EXAMPLE
+    h0 = make_state(oracle, N, 1000)
+    rng = np.random.default_rng(7)
+    phase0 = ((rng.random((N, N)) - 0.5) * 2 * 6000.0).astype(np.float32)          # up to +-955 turns
+    with capi.Ocean(N, 1) as oc:
+        oc.set_cascade(0, p["wavescale"], p["choppiness"])
+        oc.upload_state(0, h0, phase0)
+        oc.displace()                                                               # no update in between: the raw phases
+        got = oc.read_maps(0)
+        assert np.array_equal(oc.read_state(0), phase0)
+        ref = oracle.displace(h0, phase0.copy(), p["wavescale"], p["choppiness"], w=oracle.weights(N, reduced=True))
+        big = float(np.abs(ref[0][..., :3]).max())
+        assert np.isfinite(got).all()
+        assert rmse(got[0][..., :3], ref[0][..., :3]) < 1e-4 * big
+        want = phase0.copy()
+        oracle.update(want, p["wavescale"], DT)
+        oc.update(DT)
+        oc.displace()
+        assert np.array_equal(oc.read_state(0), want)
+        ref = oracle.displace(h0, want.copy(), p["wavescale"], p["choppiness"], w=oracle.weights(N, reduced=True))
+        assert rmse(oc.read_maps(0)[0][..., :3], ref[0][..., :3]) < 1e-5
+
+
 def test_cascades_are_independent(capi, oracle):
     # 4 cascades with their own seeds / wavescales in one handle == 4 single-cascade handles
     N = 256
