@@ -1758,7 +1758,10 @@ int datum_ocean_debug_sim(datum_ocean_t ctx, int cascade, float *h, float *hx, f
 
   StepArgs a = make_args(ctx, 0, nullptr);
 
-  hipLaunchKernelGGL(ocean_sim_kernel, dim3(1024), dim3(256), 0, ctx->stream, a, ctx->N, cascade, ctx->scratch, ctx->scratch + P, ctx->scratch + 2 * P);
+  if (ctx->wildphase[cascade])
+    hipLaunchKernelGGL(ocean_sim_kernel<true>, dim3(1024), dim3(256), 0, ctx->stream, a, ctx->N, cascade, ctx->scratch, ctx->scratch + P, ctx->scratch + 2 * P);
+  else
+    hipLaunchKernelGGL(ocean_sim_kernel<false>, dim3(1024), dim3(256), 0, ctx->stream, a, ctx->N, cascade, ctx->scratch, ctx->scratch + P, ctx->scratch + 2 * P);
   HIPCHECK(ctx, hipGetLastError());
 
   HIPCHECK(ctx, hipMemcpyAsync(h, ctx->scratch, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));

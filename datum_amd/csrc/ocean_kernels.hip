@@ -403,10 +403,11 @@ namespace ocean
   // one point of data/ocean.sim.comp:52-66: h~ from h0(k), h0 at the mirror index and the phase, evaluated as
   // h0(k) e^{i phase} + conj(h0(mirror) e^{i phase})  (two complex products and a conjugating add: 5 packed
   // instructions; equal to the shader's expanded form, sim.comp:65-66, up to rounding)
+  template<bool WILD>
   __device__ __forceinline__ cf sim_height_products(float2 h0k, float2 h0mk, float phase)
   {
     float sin_v, cos_v;
-    sincos_phase(phase, &sin_v, &cos_v);
+    sincos_row<WILD>(phase, &sin_v, &cos_v);        // (the row pass's own sin / cos: the stage test pins the product's arithmetic)
 
     cf const e = cf{ cos_v, sin_v };
     cf const u = cmul(cf{ h0k.x, h0k.y }, e);
@@ -1853,6 +1854,7 @@ namespace ocean
 
   // ocean.sim alone, row-major output (datum_ocean_debug_sim): h~ by the same function the row pass uses
   // (sim_height_products), so that the stage test pins the product's arithmetic, not a sibling of it
+  template<bool WILD>
   __global__ void ocean_sim_kernel(StepArgs a, int N, int cascade, cf *h, cf *hx, cf *hy)
   {
     size_t const plane = (size_t)N * N;
@@ -1865,7 +1867,7 @@ namespace ocean
     {
       int y = (int)(i / N), x = (int)(i % N);
 
-      cf hh = sim_height_products(h0[i], h0[(size_t)(N - 1 - y) * N + (N - 1 - x)], phase[i]);
+      cf hh = sim_height_products<WILD>(h0[i], h0[(size_t)(N - 1 - y) * N + (N - 1 - x)], phase[i]);
       float2 kn = knorm_of(wavevector(x, N, scale), wavevector(y, N, scale));
 
       h[i] = hh;

@@ -73,8 +73,8 @@ typedef struct datum_ocean_set
 /* -- lifetime (replaces initialise_ocean_context / prepare_ocean_context, ocean.cpp:325-716) ------------ */
 
 /* resolution: 64 (the reference's WaveResolution, ocean.h:16), 128, 256, 512, 1024, 2048 or 4096.
- * Allocates h0, phase, the work spectrum (ocean.cpp:61-68) and the 2-layer RGBA32F displacement map
- * (ocean.cpp:706) for `cascades` grids on HIP device `device`, and builds the twiddle table. */
+ * Allocates h0, phase, the work spectrum (ocean.cpp:61-68) and the 2-layer displacement map (ocean.cpp:706; stored as
+ * 24-byte texels, datum_ocean_bind_maps) for `cascades` grids on HIP device `device`, and builds the twiddle table. */
 int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int cascades);
 int datum_ocean_destroy(datum_ocean_t ctx);
 
