@@ -1239,6 +1239,10 @@ namespace ocean
 
       OCEAN_STAMP(4);
 
+#ifdef OCEAN_ROW_STORE_PRIO      // experiment: the waves that are about to store and retire go first
+      __builtin_amdgcn_s_setprio(OCEAN_ROW_STORE_PRIO);
+#endif
+
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
@@ -1574,6 +1578,10 @@ namespace ocean
       OCEAN_STAMP(3);
 
       float const nz = cc.nz;
+
+#ifdef OCEAN_COL_STORE_PRIO      // experiment: as in the row pass
+      __builtin_amdgcn_s_setprio(OCEAN_COL_STORE_PRIO);
+#endif
 
       int const o0 = MAP_COMPACT ? 0 : (int)map_index(N, t, x, 0) * 16;   // byte offset of this thread's first texel (layer 0; layer 1 is 16 MAP_GROUP bytes on)
 
