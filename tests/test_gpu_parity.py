@@ -784,6 +784,44 @@ def test_gen_split_launch_is_the_same_mesh(capi, oracle, torch, monkeypatch):
         assert torch.equal(out[0], out[1]), N
 
 
+def test_handles_come_and_go(capi, oracle, torch):
+    # 40 handles created, used (upload, update, displace, gen, pack; every fourth one farms in a one-rank communicator) and destroyed:
+    # nothing fails on the way and the device's free memory comes back (a leaked map buffer would be 6 MB each, a leaked farm 2 MB)
+    N, C = 256, 2
+    p = oracle.EXAMPLE
+    h0 = make_state(oracle, N, 1000)
+    s = oracle.example_oceanset(N, swellphase=0.2)
+    hs = capi.OceanSet.from_buffer_copy(bytes(s))
+    verts = torch.empty(64 * 64 * 12, dtype=torch.float32, device="cuda:0")
+    payload = torch.empty(C * N * N * 3, dtype=torch.float32, device="cuda:0")
+
+    def once(k):
+        with capi.Ocean(N, C) as oc:
+            for c in range(C):
+                oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c], p["choppiness"])
+                oc.upload_state(c, h0)
+            oc.update(DT)
+            oc.displace()
+            oc.gen(1, hs, 64, 64, verts.data_ptr())
+            oc.pack_displacement(capi.PAYLOAD_XYZ32, payload.data_ptr(), payload.numel() * 4)
+            if k % 4 == 0:
+                oc.farm_init(capi.farm_unique_id(), 0, 1, capi.PAYLOAD_XYZ16)
+                slot = oc.farm_gather()
+                oc.farm_wait(slot)
+                if k % 8 == 0:
+                    oc.farm_shutdown()          # (the others leave it to destroy)
+            oc.sync()
+
+    once(0)                                     # first use: lazy allocations of the runtime and of RCCL
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(40):
+        once(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)
+
+
 def test_gen_ragged_mesh(capi, oracle, torch):
     # mesh sizes that are not multiples of the 16 x 16 vertex tiles (nor of a wave's 4 rows): the staged stores must
     # neither drop nor overrun vertices (guard words after the buffer stay untouched)
