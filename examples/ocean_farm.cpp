@@ -56,7 +56,11 @@ namespace
     else if (!read_all(idin, id, sizeof(id)))
       return 1;
 
-    CHECK(datum_ocean_create(&hip, rank, N, 1));       // device = rank: one GPU per process
+    // device = rank: one GPU per process (DATUM_FARM_DEVICES = d spreads the ranks over d devices instead -- RCCL refuses two ranks
+    // on one GPU, which is how the error path of datum_ocean_farm_init is exercised on a one-GPU box)
+    int const devices = getenv("DATUM_FARM_DEVICES") ? atoi(getenv("DATUM_FARM_DEVICES")) : world;
+
+    CHECK(datum_ocean_create(&hip, rank % (devices > 0 ? devices : 1), N, 1));
 
     // this rank's tile: example-ocean parameters, seed 1000 + global tile index
     {

@@ -98,6 +98,22 @@ def test_farm_example_program(oracle):
     assert sums[0] == f"{h:016x}"
 
 
+def test_farm_example_two_ranks_on_one_gpu_fail_cleanly():
+    # Two ranks of examples/ocean_farm sent to ONE device (DATUM_FARM_DEVICES=1): the id travels from rank 0 through the parent to
+    # rank 1, both processes meet in RCCL's bootstrap -- and RCCL refuses two ranks on one GPU.  What must come out of that:
+    # datum_ocean_farm_init returns DATUM_OCEAN_ECOMM (-6) on both ranks with RCCL's own text in datum_ocean_last_error, nothing
+    # hangs, the program exits 1.  (The only part of a multi-rank farm a one-GPU box can run.)
+    exe = os.path.join(ROOT, "examples", "ocean_farm")
+    assert os.path.exists(exe), "build it with `make examples`"
+    out = subprocess.run([exe, "2", "256", "1", "2"], capture_output=True, text=True, timeout=180,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DATUM_FARM_DEVICES="1"))
+    assert out.returncode == 1
+    assert "FAILED" in out.stdout
+    for rank in (0, 1):
+        line = [l for l in out.stderr.splitlines() if l.startswith(f"rank {rank}: datum_ocean_farm_init")]
+        assert line and "(-6)" in line[0] and "ncclCommInitRank" in line[0] and "Duplicate GPU" in line[0], out.stderr
+
+
 def test_render_through_host_api_and_wave_change(oracle):
     # seed, tick, render; then change the wind (lerp_ocean_waves recomputes h0, ocean.cpp:185-213) and keep going:
     # the device keeps its phase, takes the new h0, and still matches the oracle run the same way
