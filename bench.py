@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--python-gather", action="store_true",
                     help="N > 1: issue the all-gather from Python (datum_amd/farm.py over torch.distributed) instead of the module's own "
                          "RCCL communicator (datum_ocean_farm_*); for comparison only")
+    ap.add_argument("--rendezvous", choices=("nccl", "gloo"), default="nccl",
+                    help="N > 1: the backend of the torch.distributed group that carries the farm's id, the barriers and the reduction of the "
+                         "timings (the all-gather itself is the module's own RCCL communicator either way).  gloo + DATUM_BENCH_DEVICES=1 rehearses "
+                         "an N-rank run on ONE GPU (all ranks on device 0; --gather none, or up to RCCL's refusal of two ranks on one device)")
     ap.add_argument("--cpu-baseline-child", nargs=3, metavar=("N", "CASCADES", "SECONDS"), default=None,
                     help="internal: the cpu_baseline leg, run as a child process with pinned OpenMP threads; prints one JSON object")
     return ap.parse_args()
@@ -316,6 +320,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
+    if os.environ.get("DATUM_BENCH_DEVICES"):       # rehearsals only: N ranks over fewer devices
+        local_rank %= max(1, int(os.environ["DATUM_BENCH_DEVICES"]))
+
     if args.gpus != world:      # before anything touches the GPU
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (own launcher) or under "
               f"torch.distributed.run with --nproc-per-node equal to --gpus", file=sys.stderr, flush=True)
@@ -336,7 +343,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rendezvous == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -560,7 +570,7 @@ def main():
     gather_ms = (oc.farm_wait(slot) if native else tg.last_collective_ms(slot)) if gathering else 0.0
 
     if multi:
-        t = torch.tensor([elapsed, compute_ms, gather_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, compute_ms, gather_ms], dtype=torch.float64, device=(dev if args.rendezvous == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, compute_ms, gather_ms = (float(v) for v in t.tolist())
 
@@ -617,8 +627,9 @@ def main():
                            + (f", every {every} step(s)" if every > 0 else f", once per {args.steps} steps") + ")" if args.standin_peers else "n/a (1 GPU)")),
                 "gathers_in_timed_region": gathers,
                 "collective_world_size": (dist.get_world_size() if multi else None),
-                "collective_backend": (None if not multi else (f"RCCL {farm_info['rccl_version']} through the module's C ABI (datum_ocean_farm_*), {farm_info['slots']} slots" if native
-                                                               else "RCCL through torch.distributed (datum_amd/farm.py)")),
+                "rendezvous_backend": (args.rendezvous if multi else None),
+                "collective_backend": (None if not (multi and gathering) else (f"RCCL {farm_info['rccl_version']} through the module's C ABI (datum_ocean_farm_*), {farm_info['slots']} slots" if native
+                                                                              else "RCCL through torch.distributed (datum_amd/farm.py)")),
                 "measured_on_hardware": ("this line" if world > 1 else "1 GPU"),
                 "payload": args.payload if gathering else None,
                 "payload_bytes_per_rank": pbytes if gathering else None,
