@@ -221,14 +221,16 @@ namespace ocean
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes), 0x00020000);
   }
 
+  template<int AUX = 0>
   __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
   {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, AUX));
   }
 
+  template<int AUX = 0>
   __device__ __forceinline__ float2 buf_load_f32x2(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
   {
-    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, voffset, soffset, 0));
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, voffset, soffset, AUX));
   }
 
   __device__ __forceinline__ cf buf_load_cf(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
@@ -279,6 +281,14 @@ namespace ocean
 #endif
 #ifndef OCEAN_SPEC_LOAD_AUX
 #define OCEAN_SPEC_LOAD_AUX 0
+#endif
+// (row pass: the phase is read once and overwritten, h0 is read twice -- as a pair's own row and as its neighbour's mirror row;
+//  policies other than the default measured in profiles/r04_load_policy_sweep.txt)
+#ifndef OCEAN_PHASE_LOAD_AUX
+#define OCEAN_PHASE_LOAD_AUX 0
+#endif
+#ifndef OCEAN_H0_LOAD_AUX
+#define OCEAN_H0_LOAD_AUX 0
 #endif
 
   //|---------------------- update_ocean --------------------------------------
@@ -930,9 +940,9 @@ namespace ocean
         in.hm[s] = make_float2(0.03f, 0.01f * (float)(y & 15));
 #else
         if (parts & 4)
-          in.ph[s] = buf_load_f32(rphase, e0 * 4, T * s * 4);
+          in.ph[s] = buf_load_f32<OCEAN_PHASE_LOAD_AUX>(rphase, e0 * 4, T * s * 4);
         if (parts & 1)
-          in.hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
+          in.hk[s] = buf_load_f32x2<OCEAN_H0_LOAD_AUX>(rh0, e0 * 8, T * s * 8);
         if (parts & 2)
           in.hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
 #endif
