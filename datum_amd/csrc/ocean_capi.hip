@@ -1146,7 +1146,7 @@ int datum_ocean_farm_init(datum_ocean_t ctx, void const *id, size_t idbytes, int
 
   FARMCHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
 
-  f->slots.resize(slots);
+  try { f->slots.resize(slots); } catch (...) { farm_teardown(ctx); return fail(ctx, DATUM_OCEAN_ENOMEM, "datum_ocean_farm_init: out of host memory"); }
 
   for(auto &sl : f->slots)
   {
@@ -1229,6 +1229,11 @@ int datum_ocean_farm_gather(datum_ocean_t ctx, int *slot)
   int const s = f->head;
   FarmSlot &sl = f->slots[s];
 
+  // a consumer on a stream of its own took this slot's result and never said when it was done reading: the collective below
+  // would overwrite what it may still be reading, and nothing orders the two
+  if (sl.held)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_farm_gather: the next slot's result was handed to another stream and not released (datum_ocean_farm_release)");
+
   // WAR on the payload: the collective that last READ this slot's payload must have finished before the pack overwrites it
   if (sl.launched)
     HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, sl.done, 0));
@@ -1302,6 +1307,11 @@ int datum_ocean_farm_result(datum_ocean_t ctx, int slot, void *hip_stream, int o
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   HIPCHECK(ctx, hipStreamWaitEvent(on_handle_stream ? ctx->stream : (hipStream_t)hip_stream, sl->done, 0));
 
+  // (a reader on the handle's stream is ordered before the slot's next pack, and with it before its next collective; any
+  // other stream has to release)
+  if (!on_handle_stream && (hipStream_t)hip_stream != ctx->stream)
+    sl->held = true;
+
   *gathered_device = sl->gathered;
 
   if (bytes)
@@ -1322,6 +1332,7 @@ int datum_ocean_farm_release(datum_ocean_t ctx, int slot, void *hip_stream, int 
   HIPCHECK(ctx, hipEventRecord(sl->consumed, on_handle_stream ? ctx->stream : (hipStream_t)hip_stream));
 
   sl->busy = true;
+  sl->held = false;
 
   return DATUM_OCEAN_OK;
 }

@@ -113,7 +113,8 @@ namespace ocean
     hipEvent_t done = nullptr;
     hipEvent_t consumed = nullptr;    // recorded by farm_release on the consumer's stream
     bool launched = false;            // a collective has been enqueued into this slot
-    bool busy = false;                // ... and its consumer has not released it yet (consumed is armed)
+    bool busy = false;                // a release is pending: the slot's next collective waits for `consumed`
+    bool held = false;                // the result went to a stream other than the handle's and has not been released
   };
 
   struct Farm

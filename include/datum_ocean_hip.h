@@ -182,7 +182,8 @@ int datum_ocean_pack_displacement(datum_ocean_t ctx, int format, void *payload_d
  *               *gathered_device = world x payload_bytes bytes, rank r's payload at r * payload_bytes.  A slot is gathered into
  *               again `slots` gathers later: take its result (and release it) before that
  *   release     `hip_stream` (or the handle's) has finished reading the gathered buffer up to this point: the slot's next
- *               collective waits for it.  Needed whenever a consumer reads on a stream of its own.
+ *               collective waits for it.  Needed whenever a consumer reads on a stream of its own: a gather that comes round to
+ *               a slot whose result went to another stream and was not released fails with DATUM_OCEAN_ESTATE.
  *   query       DATUM_OCEAN_OK once the slot's collective has finished, DATUM_OCEAN_ENOTREADY before; never blocks
  *   wait        blocks the host until it has; *collective_ms (may be NULL) = its duration on the communication stream
  *   shutdown    destroys communicator, stream and buffers (datum_ocean_destroy does it too)

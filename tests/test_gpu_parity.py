@@ -1094,9 +1094,19 @@ def test_native_farm_one_rank(capi, oracle, torch):
             with pytest.raises(capi.OceanError) as e:
                 oc.farm_gather()
             assert e.value.code == capi.ESTATE
-            oc.farm_init(capi.farm_unique_id(), 0, 1, code)       # and again after a shutdown; destroy tears it down
+            oc.farm_init(capi.farm_unique_id(), 0, 1, code)       # and again after a shutdown
+            held = oc.farm_gather()
+            oc.farm_result(held, consumer.cuda_stream)            # handed to another stream and never released ...
             oc.farm_gather()
-            oc.set_stream(None)
+            with pytest.raises(capi.OceanError) as e:
+                oc.farm_gather()                                  # ... the gather that comes round to that slot refuses
+            assert e.value.code == capi.ESTATE and "released" in str(e.value)
+            oc.farm_release(held, consumer.cuda_stream)
+            assert oc.farm_gather() == held
+            oc.farm_result(held)                                  # (a reader on the handle's own stream needs no release)
+            oc.farm_gather()
+            assert oc.farm_gather() == held
+            oc.set_stream(None)                                   # destroy tears the farm down
 
 
 def _device_view(torch, ptr, numel, dtype):
