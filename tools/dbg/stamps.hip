@@ -20,7 +20,10 @@ int main() {
 #ifndef STAMP_C
 #define STAMP_C 4
 #endif
-  constexpr int N = STAMP_N, C = STAMP_C; size_t P = (size_t)N*N;
+#ifndef STAMP_H16
+#define STAMP_H16 false
+#endif
+  constexpr int N = STAMP_N, C = STAMP_C; constexpr bool H = STAMP_H16; typedef RowCfg<N, H> RC; constexpr bool RW = RC::WALK, CW = (N >= OCEAN_COL_WALK_FROM); size_t P = (size_t)N*N;
   StepArgs a{};
   float2 *h0; float *phase; cd *spec; cf *tw; float4 *maps; float *omega; unsigned long long *stamps;
   CK(hipMalloc(&h0, C*P*8)); CK(hipMalloc(&phase, C*P*4)); CK(hipMalloc(&spec, C*P*16)); CK(hipMalloc(&maps, C*2*P*16));
@@ -33,11 +36,11 @@ int main() {
     std::vector<cf> t(N); for (int k=0;k<N;++k) t[k] = cf{(float)cos(2*M_PI*k/N),(float)sin(2*M_PI*k/N)}; CK(hipMemcpy(tw, t.data(), N*8, hipMemcpyHostToDevice)); }
   a.h0=h0; a.phase=phase; a.spec=spec; a.maps=maps; a.tw=tw; a.omega=omega; a.ndt=1; a.cascades=C; a.dt[0]=1.f/60; a.stamps=stamps;
   for (int c=0;c<DATUM_OCEAN_MAX_CASCADES;++c) a.casc[c] = CascadeConst{22.f, 1/22.f, 1.35f, 4/(N/22.f), 1.f, 1.f};
-  CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N>::LDS));
-  CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS));
+  CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC::LDS));
+  CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS));
   for (int it = 0; it < 5; ++it) {
-    hipLaunchKernelGGL((ocean_rowpass_kernel<N, false>), dim3(row_walks<N>() ? 256 : RowCfg<N>::GROUPS * C), dim3(RowCfg<N>::THREADS), RowCfg<N>::LDS, 0, a);
-    hipLaunchKernelGGL((ocean_colpass_kernel<N, false>), dim3(col_walks<N, false>() ? 256 : ColCfg<N>::TILES * C), dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, 0, a);
+    hipLaunchKernelGGL((ocean_rowpass_kernel<N, H>), dim3(RW ? 256 : RC::GROUPS * C), dim3(RC::THREADS), RC::LDS, 0, a);
+    hipLaunchKernelGGL((ocean_colpass_kernel<N, H>), dim3(CW ? 256 : ColCfg<N>::TILES * C), dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, 0, a);
   }
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> st(nst); CK(hipMemcpy(st.data(), stamps, nst*8, hipMemcpyDeviceToHost));
@@ -71,7 +74,7 @@ int main() {
     for (auto &kv : bycu) { if (shown++ >= 2) break; printf("   CU %06x:", kv.first); auto v = kv.second; std::sort(v.begin(), v.end(), [&](int x, int y){ return st[(base+x)*16] < st[(base+y)*16]; });
       for (int b : v) { auto *s = &st[(base + b) * 16]; printf("  [wg %d:", b); for (int k = 0; k <= nph; ++k) printf(" %.1f", (s[k] - t0) * 0.01); printf("]"); } printf("\n"); }
   };
-  analyse("rowpass", 0, row_walks<N>() ? 256 : RowCfg<N>::GROUPS * C, 5, {"start -> inputs arrived", "advance + phase stores + sim + swap barrier", "build C, D + barrier", "2-field transform (6 barriers)", "spectrum stores issued"});
-  analyse("colpass", 65536, col_walks<N, false>() ? 256 : ColCfg<N>::TILES * C, 4, {"start -> inputs arrived", "2-field transform (6 barriers)", "height exchange + barrier", "normals + map stores issued"});
+  analyse("rowpass", 0, RW ? 256 : RC::GROUPS * C, 5, {"start -> inputs arrived", "advance + phase stores + sim + swap barrier", "build C, D + barrier", "2-field transform (6 barriers)", "spectrum stores issued"});
+  analyse("colpass", 65536, CW ? 256 : ColCfg<N>::TILES * C, 4, {"start -> inputs arrived", "2-field transform (6 barriers)", "height exchange + barrier", "normals + map stores issued"});
   return 0;
 }
