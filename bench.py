@@ -334,6 +334,13 @@ def main():
     if args.plumbing:
         return plumbing(rank, world)
 
+    # File descriptor 1 is kept for the ONE JSON line.  Libraries write to stdout too -- RCCL prints a version banner through C stdio when
+    # a communicator is made, and in a pipe that buffer is flushed at exit, i.e. BEHIND the line -- so everything else of this process
+    # goes to stderr from here on.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -477,6 +484,21 @@ def main():
 
     row_ms, col_ms, nprof = oc.profile_end()
 
+    # SURVEY.md 8e asks for both figures: with the gather (the timed region above, `value`) and the tiles' throughput without it.
+    # The same K steps once more, outside the timed region, no pack and no collective in flight; max over ranks like `value`.
+    plain_elapsed = 0.0
+    if multi and gathering:
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        plain_elapsed = time.perf_counter() - t1
+
     # Beyond the Infinity Cache (outside the timed region): the headline's working set, 1024^2 x 4 = 252 MB, fits the 256 MiB
     # Infinity Cache and its kernels run above what HBM alone delivers; the same kernels over 16 cascades (1 GB) cannot.  Ten
     # steps after five, every step's two kernels timed with dispatch events, fractions on ALGORITHMIC bytes like `roofline`.
@@ -570,9 +592,9 @@ def main():
     gather_ms = (oc.farm_wait(slot) if native else tg.last_collective_ms(slot)) if gathering else 0.0
 
     if multi:
-        t = torch.tensor([elapsed, compute_ms, gather_ms], dtype=torch.float64, device=(dev if args.rendezvous == "nccl" else "cpu"))
+        t = torch.tensor([elapsed, compute_ms, gather_ms, plain_elapsed], dtype=torch.float64, device=(dev if args.rendezvous == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, compute_ms, gather_ms = (float(v) for v in t.tolist())
+        elapsed, compute_ms, gather_ms, plain_elapsed = (float(v) for v in t.tolist())
 
     if rank == 0:
         # sanity: the maps of the last step are finite and non-trivial
@@ -667,6 +689,10 @@ def main():
             "gen": gen,
             "reference_frame_n64": frame,
             "value_compute_only": grids / (compute_ms * 1e-3) if (compute_ms > 0 and args.gather != "serial") else None,
+            "without_gather": ({"value": grids / plain_elapsed, "unit": "grids/s", "ms_per_step": plain_elapsed * 1e3 / args.steps,
+                                "what": f"the same {args.steps} steps once more after the timed region with no pack and no collective in flight, timed the same way "
+                                        "(barriers, max over ranks): the tiles' own throughput (SURVEY.md 8e (i)); `value` is the figure WITH the gather (8e (ii))"}
+                               if plain_elapsed > 0 else None),
         }
 
         if world == 1 and args.cpu_seconds > 0:
@@ -674,7 +700,7 @@ def main():
         else:
             line["cpu_baseline"] = None
 
-        print(json.dumps(line), flush=True)
+        os.write(line_fd, (json.dumps(line) + "\n").encode())
 
     oc.bind_maps(0, 0)
     oc.set_stream(None)

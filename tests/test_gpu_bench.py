@@ -51,3 +51,20 @@ def test_the_gather_reaches_rccl_and_fails_cleanly():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]              # no JSON line from a failed run
     assert "Duplicate GPU" in r.stderr and "datum_ocean error -6" in r.stderr and "ranks failed" in r.stderr
+
+
+def test_one_rank_group_with_the_native_gather():
+    # --force-collective: the N > 1 code path in a one-rank group on the real backends (RCCL process group, the module's own
+    # communicator, pack + all-gather on the communication stream inside the timed region), then the same steps without the gather
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, BENCH, "--force-collective", "--steps", "6", "--warmup", "2", "--cpu-seconds", "0", "--no-frame", "--no-regime",
+                        "--resolution", "512", "--cascades", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # stdout is the ONE JSON line and nothing else: RCCL's version banner (C stdio, flushed at exit, i.e. behind the line) goes to stderr
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout[-600:]
+    j = json.loads(r.stdout)
+    assert j["n_gpus"] == 1 and j["config"]["gathers_in_timed_region"] == 1 and j["config"]["payload"] == "xyz32"
+    assert "datum_ocean_farm_" in j["config"]["collective_backend"] and j["config"]["payload_bytes_per_rank"] == 512 * 512 * 2 * 12
+    assert j["gather_ms"] > 0 and j["value"] > 0
+    assert j["without_gather"]["value"] > 0 and j["without_gather"]["ms_per_step"] > 0
