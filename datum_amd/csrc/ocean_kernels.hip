@@ -756,14 +756,22 @@ namespace ocean
 #define OCEAN_ROW_EARLY 3          // walking row pass: the parts of the next pair's inputs requested BEFORE the transforms (see request): h0 and its mirror row
 #endif
 
+  // 2048^2 (round 4, profiles/r04_structure_variants.txt): the 1024^2 column pass's recipe in the row pass -- 16 points per thread (2048 = 16 x 16 x 8:
+  // three passes, two exchanges instead of four and three), the two fields one after the other through one LDS line per row (35 KB
+  // per 256-thread pair), three workgroups per CU at 144 registers, no spill: row pass 31.2 -> 28.6 us (x 1), 118.9 -> 112.2 us (x 4),
+  // with the fp16-stored spectrum 29.1 -> 25.7 us.  Not at 1024^2 (28.9 against 25.2 us), not with four per CU (128 registers, 72 bytes
+  // of spill: 33.8 us), not without the sequential fields (65 KB, two 4-wave workgroups per CU: 31.2 us).
 #ifndef OCEAN_ROW_E16_FROM
-#define OCEAN_ROW_E16_FROM 4096      // row pass: 16 points per thread from this resolution up (half the threads per row pair)
+#define OCEAN_ROW_E16_FROM 2048      // row pass: 16 points per thread from this resolution up (half the threads per row pair)
 #endif
 #ifndef OCEAN_ROW_SEQ_FROM
-#define OCEAN_ROW_SEQ_FROM 4096      // row pass: the two packed fields one after the other through ONE LDS line per row (half the LDS)
+#define OCEAN_ROW_SEQ_FROM 2048      // row pass: the two packed fields one after the other through ONE LDS line per row (half the LDS)
 #endif
 #ifndef OCEAN_ROW_SEQ_FP32
-#define OCEAN_ROW_SEQ_FP32 0         // ... with the fp32-stored spectrum too
+#define OCEAN_ROW_SEQ_FP32 0         // ... with the fp32-stored spectrum too, at every such resolution (4096^2: spills, 155 against 132 us walking)
+#endif
+#ifndef OCEAN_ROW_SEQ_FP32_AT
+#define OCEAN_ROW_SEQ_FP32_AT 2048   // ... at this resolution
 #endif
 
   template<int N, bool H16 = false>
@@ -781,11 +789,14 @@ namespace ocean
     static constexpr int THREADS = 2 * T * PAIRS;
     // one field per set of barrier phases, the other waits in registers -- with the fp16-stored spectrum only: as halves C's
     // results wait in 16 registers, as floats in 32 and the kernel spills (4096^2 fp32: 155 against 132 us)
-    static constexpr bool SEQ = (N >= OCEAN_ROW_SEQ_FROM) && (H16 || OCEAN_ROW_SEQ_FP32);
+    static constexpr bool SEQ = (N >= OCEAN_ROW_SEQ_FROM) && (H16 || OCEAN_ROW_SEQ_FP32 || N == OCEAN_ROW_SEQ_FP32_AT);
     static constexpr int K = SEQ ? 1 : 2;                                  // LDS lines per row
     // the prologue two slots per instruction -- not in the sequential form, whose registers are full (4096^2 fp16: 56 bytes of
     // spill and 134 us packed against 28 bytes and 124-128 us: profiles/r04_rowpass_packed.txt)
-    static constexpr bool PACKED = (OCEAN_ROW_PACKED != 0) && !SEQ;
+#ifndef OCEAN_ROW_PACKED_SEQ_AT
+#define OCEAN_ROW_PACKED_SEQ_AT 0      // experiments: ... but in the sequential form at this resolution
+#endif
+    static constexpr bool PACKED = (OCEAN_ROW_PACKED != 0) && (!SEQ || N == OCEAN_ROW_PACKED_SEQ_AT);
     static constexpr int PS = 4;
     static constexpr int LINE = LineFFT<N, PS, E>::LINE + 2;               // + element 0 again at index N (the Hermitian swap), kept 16-byte aligned
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
@@ -801,7 +812,11 @@ namespace ocean
 #ifndef OCEAN_ROW_SEQ_MAX_PER_CU
 #define OCEAN_ROW_SEQ_MAX_PER_CU 4
 #endif
-    static constexpr int MIN_WAVES = WALK ? (THREADS / 64) * PER_CU / 4 : (SEQ ? ((THREADS / 64) * (FIT > OCEAN_ROW_SEQ_MAX_PER_CU ? OCEAN_ROW_SEQ_MAX_PER_CU : FIT) + 3) / 4 : 1);   // per SIMD, for __launch_bounds__
+#ifndef OCEAN_ROW_SEQ_MAX_PER_CU_2048
+#define OCEAN_ROW_SEQ_MAX_PER_CU_2048 3
+#endif
+    static constexpr int SEQ_PER_CU = (N == 2048) ? OCEAN_ROW_SEQ_MAX_PER_CU_2048 : OCEAN_ROW_SEQ_MAX_PER_CU;     // sequential form: workgroups per CU the registers are budgeted for
+    static constexpr int MIN_WAVES = WALK ? (THREADS / 64) * PER_CU / 4 : (SEQ ? ((THREADS / 64) * (FIT > SEQ_PER_CU ? SEQ_PER_CU : FIT) + 3) / 4 : 1);   // per SIMD, for __launch_bounds__
 
     static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
   };
