@@ -404,6 +404,7 @@ OceanParams::OceanParams(int resolution)
     seed((size_t)resolution * resolution * 2, 0.0f),
     height((size_t)resolution * resolution * 2, 0.0f),
     phase((size_t)resolution * resolution, 0.0f),
+    hostphase(resolution <= OceanContext::WaveResolution),
     stateid(g_stateids++)
 {
 }

@@ -10,7 +10,9 @@
 //   2. The Vulkan objects of OceanContext are replaced by one opaque HIP-module handle
 //      (include/datum_ocean_hip.h); VkSemaphore dependencies become hipEvent_t handles (void*).
 //   3. update_ocean's phase loop (ocean.cpp:223-233) runs on the device: update_ocean() queues dt,
-//      render_ocean_surface() applies the queue in order, bit-identically.  OceanParams::phase on the host
+//      render_ocean_surface() applies the queue in order, bit-identically.  At the reference's own resolution
+//      (N <= 64) update_ocean ALSO runs the loop on the host, as the reference does (OceanParams::hostphase, on by
+//      default there: OceanParams::phase is current after every call); above it OceanParams::phase on the host
 //      is the state as of the last fetch_ocean_state().
 // Device failures throw std::runtime_error as the reference does (ocean.cpp:271, vulkan.cpp:550);
 // misuse trips assert (ocean.cpp:351,722-723); prepare_ocean_context returns bool (ocean.cpp:493-501).
@@ -211,9 +213,13 @@ struct OceanParams
   // then stale until fetch_ocean_state().  Off by default (the reference recomputes on the host).
   bool deviceheight = false;
 
-  // extension: also advance `phase` on the host in every update_ocean call, as the reference does (ocean.cpp:223-233; N * N
-  // fmod per call).  Off by default: the phase lives on the device (and in the contexts' parked copies); the host copy is
-  // the state as of seed_ocean / the last fetch_ocean_state and is only needed by a context that holds no copy.
+  // Also advance `phase` on the host in every update_ocean call, as the reference does (ocean.cpp:223-233; N * N fmod per call).
+  // ON by default at the reference's own resolution (N <= WaveResolution = 64: 33 us per call) -- there an OceanParams behaves
+  // exactly like the reference's: `phase` is current after every update_ocean, any context renders any params at any time,
+  // to_pod() always succeeds -- and OFF above it (the constructor decides), where the N * N host loop is what had to leave the
+  // CPU: the phase lives on the device (and in the contexts' parked copies), the host copy is the state as of seed_ocean /
+  // the last fetch_ocean_state and is only needed by a context that holds no copy.  Either way the device advances its own
+  // copy (the row-pass kernel, bit for bit the same values).
   bool hostphase = false;
 
   // device residency bookkeeping (not in the reference)
@@ -225,8 +231,8 @@ struct OceanParams
   // rendering is const: render_ocean_surface applies the entries the CONTEXT has not applied yet
   // (OceanContext::appliedupdates) and never touches the params.  The history keeps the last MaxRecordedUpdates entries.  A
   // context that alternates between several params parks the one it is not rendering (OceanContext::Parked) and continues
-  // from there; only a context that holds NO copy of a state whose host phase is older than the recorded history throws
-  // (render or fetch a state every MaxRecordedUpdates / 2 steps, or set hostphase).
+  // from there; without hostphase (N > 64, or switched off) a context that holds NO copy of a state whose host phase is older
+  // than the recorded history throws (render or fetch a state every MaxRecordedUpdates / 2 steps, or set hostphase).
   // (lineage: a running hash over the history up to and including this entry.  A copy of an OceanParams that is then
   // advanced on its own -- update_ocean(P, a), update_ocean(Q, b) -- shares P's stateid and history NUMBERS but not their
   // contents; a context tells the two apart by the lineage of the last entry it applied.)

@@ -97,8 +97,21 @@ def test_update_ocean_scalars_and_queue(host, oracle):
     s = p.scalars()
     assert s.swellphase == np.float32(sp)
     assert tuple(s.flow) == tuple(np.float32(v) for v in fl)
-    assert s.pending == 50  # the phase advance itself waits for the device: 50 recorded steps
-    assert np.all(p.phase == 0)
+    assert s.pending == 50  # the device's phase advance waits for the next render: 50 recorded steps
+    # at the reference's own resolution the host copy of the phase follows every call, as in the reference (hostphase defaults to on
+    # for N <= 64): bit for bit the oracle's loop
+    phase = np.zeros((64, 64), np.float32)
+    for i in range(50):
+        oracle.update(phase, e["wavescale"], np.float32(1 / 60 + 0.001 * i))
+    assert np.array_equal(p.phase, phase)
+    # switched off (and by default above 64 x 64) the phase lives on the device only
+    for q in (host.OceanParams(64, **host.EXAMPLE_TUNABLES), host.OceanParams(128, **host.EXAMPLE_TUNABLES)):
+        if q.N == 64:
+            q.set_hostphase(False)
+        q.seed_ocean(1000)
+        for i in range(5):
+            q.update_ocean(np.float32(1 / 60))
+        assert q.scalars().pending == 5 and np.all(q.phase == 0)
 
 
 def test_oceanset_header_matches_oracle(host, oracle):
@@ -164,6 +177,7 @@ def test_hostphase_switched_on_after_the_history_was_trimmed(host):
     # updates[phaseupdates - firstupdate] with phaseupdates < firstupdate (an unsigned underflow: out of bounds).  Now the
     # setter refuses, and the bare field -- as C++ code would set it -- makes update_ocean throw and leave the params as it was.
     p = host.OceanParams(32, **host.EXAMPLE_TUNABLES)
+    p.set_hostphase(False)                        # (on by default at N <= 64)
     p.seed_ocean(1000)
     dt = np.float32(1 / 60)
     for _ in range(4300):
@@ -185,6 +199,7 @@ def test_hostphase_switched_on_after_the_history_was_trimmed(host):
     assert p.scalars().swellphase != sp
     # switched on in time (history intact) it catches up in one call
     q = host.OceanParams(32, **host.EXAMPLE_TUNABLES)
+    q.set_hostphase(False)
     q.seed_ocean(1000)
     for _ in range(100):
         q.update_ocean(dt)
@@ -216,13 +231,14 @@ def test_reference_pod_round_trip(host):
     assert np.array_equal(q.seed, p.seed) and np.array_equal(q.height, p.height) and np.array_equal(q.phase, p.phase)
     assert bytes(q.scalars())[:ctypes.sizeof(host.Scalars) - 12] == bytes(p.scalars())[:ctypes.sizeof(host.Scalars) - 12]
     assert q.to_pod() == pod
-    p.update_ocean(np.float32(1 / 60))                                # recorded, not in the host phase: the POD would be stale
-    assert p.to_pod() is None
-    h = host.OceanParams(64, **host.EXAMPLE_TUNABLES)
-    h.seed_ocean(1000)
-    h.set_hostphase(True)
-    h.update_ocean(np.float32(1 / 60))                                # with hostphase the host copy is current after every call
-    pod2 = h.to_pod()
+    p.update_ocean(np.float32(1 / 60))                                # the host copy is current after every call (hostphase: the default at 64 x 64)
+    pod2 = p.to_pod()
     assert pod2 is not None and np.any(np.frombuffer(pod2, np.float32)[o + 16384:o + 20480] != 0)
+    h = host.OceanParams(64, **host.EXAMPLE_TUNABLES)
+    h.set_hostphase(False)
+    h.seed_ocean(1000)
+    assert h.to_pod() is not None
+    h.update_ocean(np.float32(1 / 60))                                # without it: recorded, not in the host phase -- the POD would be stale
+    assert h.to_pod() is None
     with pytest.raises(host.HostError):
         host.OceanParams(128).to_pod()

@@ -60,8 +60,7 @@ for q in range(sequences):
         tun = dict(host_api.EXAMPLE_TUNABLES, wavescale=float(np.exp(rng.uniform(np.log(6.0), np.log(300.0)))), waveamplitude=float(0.0025 * 10.0 ** rng.uniform(-0.7, 0.7)))
         p = host_api.OceanParams(N, **tun)
         hp = bool(rng.random() < 0.25)
-        if hp:
-            p.set_hostphase(True)
+        p.set_hostphase(hp)             # (explicitly: on by default at 64 x 64 only)
         p.seed_ocean(5000 + 97 * q + k)
         return Model(p, np.zeros((N, N), np.float32), hp)
 
