@@ -14,7 +14,6 @@ Tolerances (fp32 path; north_star: displacement RMSE < 1e-5):
   * ocean.gen: position abs error < 2e-4 * (1 + |p|) (ray/plane distances reach 1e3..1e6), unit vectors < 2e-4.
 """
 
-import ctypes
 
 import numpy as np
 import pytest

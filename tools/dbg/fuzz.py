@@ -30,7 +30,6 @@ def rmse(a, b):
 
 
 worst = dict(maps=0.0, normal=0.0, pos=0.0, frame=0.0)
-only = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None
 for k in range(cases):
     N = int(rng.choice([64, 128, 256, 512, 1024], p=[0.25, 0.25, 0.25, 0.15, 0.10])) if not os.environ.get("FUZZ_SIZES") else int(rng.choice([int(v) for v in os.environ["FUZZ_SIZES"].split(",")]))
     C = int(rng.integers(1, 4)) if N <= 1024 else int(rng.integers(1, 3))
