@@ -434,9 +434,9 @@ def main():
     # kernel durations for the roofline: HIP events around the two kernels of every `stride`-th step of the timed loop, on
     # the stream they run on.  A sampled step costs the loop ~6 us (the events ride on the dispatch packets, but the next
     # dispatch is not prepared under a sampled one's tail): at 20 steps every 2nd step sampled takes 6 % off the
-    # throughput being measured, every 4th 3 %, every 8th 1.5 % (tools/stride_check.sh) -- every 4th there (5 samples of each
-    # kernel), every 8th from 64 steps up (DATUM_BENCH_STRIDE overrides)
-    stride = int(os.environ.get("DATUM_BENCH_STRIDE", "0")) or (8 if args.steps >= 64 else (4 if args.steps >= 16 else 1))
+    # throughput being measured, every 4th 3 %, every 8th 1.5 % (tools/stride_check.sh) -- about 5 samples of each kernel below
+    # 64 steps (every 4th step at the driver's 20), every 8th step from 64 steps up (DATUM_BENCH_STRIDE overrides)
+    stride = int(os.environ.get("DATUM_BENCH_STRIDE", "0")) or (8 if args.steps >= 64 else max(1, args.steps // 5))
     oc.profile_begin((args.steps + stride - 1) // stride, stride)
     ev0, ev1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
 
