@@ -610,14 +610,23 @@ def main():
         pts = float(N) * N * C
         texel = capi.map_layout(N)[3]
         moved = ((24.0 if args.spectrum == "fp16" else 32.0) * pts, ((8.0 if args.spectrum == "fp16" else 16.0) + texel) * pts)
-        # the dominant kernel: the longer of the two; within 3 % of each other (1024^2 x 4 since round 4: 25.2 and 25.7 us) the
-        # column pass, which carries more of the algorithmic bytes, so that the field does not flip from run to run
-        dom = ("colpass", col_ms, col_b) if col_ms >= 0.97 * row_ms else ("rowpass", row_ms, row_b)
-        ach = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+        # the dominant kernel: strictly the longer of the two (round 5; round 4's tie-break towards the column pass picked the
+        # kernel with the larger figure: ADVICE r04)
+        dom = ("colpass", col_ms, col_b, moved[1]) if col_ms > row_ms else ("rowpass", row_ms, row_b, moved[0])
         step_ach = (row_b + col_b) / ((row_ms + col_ms) * 1e-3) / 1e9 if row_ms + col_ms > 0 else 0.0
 
         kernel_name = f"ocean_{dom[0]}_kernel<{N}>"
         traffic, traffic_source = measured_traffic(kernel_name, f"{N}x{N} x {C} cascades") if args.spectrum == "fp32" else (None, None)
+        # roofline.frac is a PHYSICAL fraction (<= 1 by construction): the bytes that cross the L2's memory side per launch -- the PMC
+        # figure for this kernel, workload and kernel source when profiles/ holds one, otherwise the bytes the kernel moves by design
+        # (the two agree within 3 % wherever both exist) -- over the launch duration measured here over 8 TB/s.  The figure on SURVEY
+        # 8d's ALGORITHMIC bytes (which the kernels do not all move) is kept beside it as frac_on_survey_bytes.
+        phys_bytes = float(traffic) if traffic is not None else dom[3]
+        ach = phys_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+        survey_ach = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+        # h0 8 + phase 4 + work spectrum 16 (8 as halves) + maps: what one step touches
+        working_set = ((20.0 if args.spectrum == "fp16" else 28.0) + texel) * pts
+        residency = "infinity-cache" if working_set < 256 * 2**20 else "hbm"
 
         line = {
             "metric": "ocean grids/sec (N x N displacement step)",
@@ -666,16 +675,26 @@ def main():
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
-                "note": ("frac is ALGORITHMIC bytes (SURVEY.md 8d: 96 B/pt fp32, 68 fp16-stored; this kernel's share in bytes_per_launch) over the measured launch "
-                         "duration over 8 TB/s. It can pass 1.0: the kernels move fewer bytes than the algorithm as the reference states it -- two packed "
-                         "transforms instead of three (16 instead of 24 B/pt between the passes) and 24-byte texels (the constant-zero .w channels are not "
-                         "stored) -- and at 1024^2 x 4 the working set (218 MB) sits inside the 256 MiB Infinity Cache. frac_of_peak_on_bytes_moved is the "
-                         "rate on the bytes that really move; hbm_regime the same kernels beyond the cache."),
+                "frac_basis": ("rocprofv3 PMC bytes per launch (traffic)" if traffic is not None else "bytes moved by design (no committed PMC pass for these kernel sources)"),
+                "residency": residency,
+                "working_set_bytes": working_set,
+                "achieved_on_survey_bytes": survey_ach,
+                "frac_on_survey_bytes": survey_ach / HBM_PEAK_GBS,
+                "frac_hbm_regime_on_bytes_moved": (regime["frac_on_bytes_moved"] if regime else None),
+                "note": ("frac = the dominant (longer) kernel's bytes across the L2's memory side per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE where "
+                         "profiles/ holds a pass of these kernel sources, else the bytes moved by design) / ms_per_launch / 8 TB/s. "
+                         "frac_on_survey_bytes is the same duration on SURVEY.md 8d's ALGORITHMIC bytes (96 B/pt fp32, 68 fp16-stored; this "
+                         "kernel's share in bytes_per_launch); it can pass 1.0 because the kernels move fewer bytes than the algorithm as the "
+                         "reference states it -- two packed transforms instead of three (16 instead of 24 B/pt between the passes) and 24-byte "
+                         "texels (the constant-zero .w channels are not stored). residency says where the working set lives: at 1024^2 x 4 "
+                         "(218 MB) inside the 256 MiB Infinity Cache, so frac is a fabric rate there; frac_hbm_regime_on_bytes_moved is the same "
+                         "two kernels over 16 cascades (1 GB), out of HBM."),
                 "hbm_bytes_by_design": {"rowpass": moved[0], "colpass": moved[1]},
                 "frac_of_peak_on_bytes_moved": {"rowpass": moved[0] / (row_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if row_ms > 0 else None,
                                                 "colpass": moved[1] / (col_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if col_ms > 0 else None,
                                                 "step": (moved[0] + moved[1]) / ((row_ms + col_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS if row_ms + col_ms > 0 else None},
-                "bytes_per_launch": dom[2],
+                "bytes_per_launch": phys_bytes,
+                "survey_bytes_per_launch": dom[2],
                 "ms_per_launch": dom[1],
                 "rowpass": {"ms": row_ms, "bytes": row_b, "GBps": row_b / (row_ms * 1e-3) / 1e9 if row_ms > 0 else 0.0},
                 "colpass": {"ms": col_ms, "bytes": col_b, "GBps": col_b / (col_ms * 1e-3) / 1e9 if col_ms > 0 else 0.0},

@@ -35,6 +35,10 @@ def test_two_ranks_without_the_gather():
     assert j["n_gpus"] == 2 and j["config"]["grids_per_step"] == 4 and j["config"]["collective_world_size"] == 2
     assert j["value"] > 0 and j["scaling"] == "weak" and j["config"]["gather"] == "none" and j["cpu_baseline"] is None
     assert j["roofline"]["rowpass"]["ms"] > 0 and j["roofline"]["colpass"]["ms"] > 0
+    # a physical fraction: bytes moved (PMC or by design) over the longer kernel's duration over the peak
+    rf = j["roofline"]
+    assert 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["bytes_per_launch"] / (rf["ms_per_launch"] * 1e-3) / 8e12) < 1e-9
+    assert rf["ms_per_launch"] == max(rf["rowpass"]["ms"], rf["colpass"]["ms"]) and rf["residency"] in ("infinity-cache", "hbm")
 
 
 def test_under_torch_distributed_run():
