@@ -602,8 +602,8 @@ namespace ocean
 
   template<int N, int E_> struct LineTw
   {
-    typedef typename LineFFT<N, 4, E_>::Twiddles type;
-    static __device__ __forceinline__ void load(cf const *tw, int t, type &w) { LineFFT<N, 4, E_>::load_twiddles(tw, t, w); }
+    typedef typename LineFFT<N, 1, E_>::Twiddles type;
+    static __device__ __forceinline__ void load(cf const *tw, int t, type &w) { LineFFT<N, 1, E_>::load_twiddles(tw, t, w); }
   };
 
   //|---------------------- line FFTs with workgroup barriers ------------------
@@ -614,10 +614,11 @@ namespace ocean
 
   // `before_last` runs between the last exchange and the last pass: every value of the lines is in LDS then and the
   // threads' value registers are free (the walking column pass requests its next tile there)
-  template<int N, int K, int PS, int E_, typename Hook = NoHook>
+  // W: lines interleaved element by element (`line` points at this thread's line, element positions W apart): LineFFT
+  template<int N, int K, int W, int E_, typename Hook = NoHook>
   __device__ __forceinline__ void fft_lines(cf (&v)[K][E_], int t, cf *line, int linestride, cf const *midtab, typename LineTw<N, E_>::type const &w, bool active, Hook before_last = Hook())
   {
-    typedef LineFFT<N, PS, E_> L;
+    typedef LineFFT<N, W, E_> L;
 
     if (active)
     {
@@ -797,12 +798,11 @@ namespace ocean
 #define OCEAN_ROW_PACKED_SEQ_AT 0      // experiments: ... but in the sequential form at this resolution
 #endif
     static constexpr bool PACKED = (OCEAN_ROW_PACKED != 0) && (!SEQ || N == OCEAN_ROW_PACKED_SEQ_AT);
-    static constexpr int PS = 4;
-    static constexpr int LINE = LineFFT<N, PS, E>::LINE + 2;               // + element 0 again at index N (the Hermitian swap), kept 16-byte aligned
+    static constexpr int LINE = LineFFT<N, 1, E>::LINE;                    // >= N + 2: element 0 once more at index N (the Hermitian swap)
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
     static constexpr bool WALK = (N >= OCEAN_ROW_WALK_FROM) && PAIRS == 1 && !SEQ;       // see ocean_rowpass_kernel
     static constexpr int STASH = 1 + LineTwiddles<N, E>::NMIDREG + Plan<N, E>::M;             // per-thread twiddles the walking variant keeps in LDS between pairs
-    static constexpr size_t LDS = ((size_t)LineFFT<N, 4, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)STASH * T : 0)) * sizeof(cf);
+    static constexpr size_t LDS = ((size_t)LineFFT<N, 1, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)STASH * T : 0)) * sizeof(cf);
 
     static constexpr int FIT = (int)(((size_t)160 * 1024) / LDS);                              // workgroups per CU the LDS allows
 #ifndef OCEAN_ROW_WALK_PER_CU
@@ -884,7 +884,7 @@ namespace ocean
   {
     typedef RowCfg<N, H16> C;
     typedef Plan<N, C::E> P;
-    typedef LineFFT<N, 4, C::E> L;
+    typedef LineFFT<N, 1, C::E> L;
 
     constexpr int E = P::E;
     constexpr int T = P::T;
@@ -915,7 +915,7 @@ namespace ocean
     constexpr int DBO = (int)(blocked<N>(0, T) - blocked<N>(0, 0));
 
     static_assert(T % SBC == 0, "slots must be whole blocks apart");
-    static_assert(T % (1 << C::PS) == 0, "slot-to-slot LDS offsets must be constants");
+    static_assert(C::LINE >= N + 2 && C::LINE % 2 == 0, "the Hermitian swap fits the line; lines stay 16-byte aligned");
 
     typedef typename SpecValue<H16>::type SV;
 
@@ -1127,7 +1127,7 @@ namespace ocean
 
           h[s + i] = add_conj(cmul(cf{ hk[s + i].x, hk[s + i].y }, e), cmul(cf{ hm[s + i].x, hm[s + i].y }, e));
 
-          swap_out[padidx<C::PS>(t + T * (s + i))] = h[s + i];
+          swap_out[t + T * (s + i)] = h[s + i];
         }
       }
       }
@@ -1143,13 +1143,13 @@ namespace ocean
 
         h[s] = add_conj(cmul(cf{ hk[s].x, hk[s].y }, e), cmul(cf{ hm[s].x, hm[s].y }, e));      // sim_height_products
 
-        swap_out[padidx<C::PS>(t + T * s)] = h[s];
+        swap_out[t + T * s] = h[s];
       }
       }
 
       // element 0 once more at index N: the partner of x is N - x for every x, without a wrap
       if (t == 0)
-        swap_out[padidx<C::PS>(N)] = h[0];
+        swap_out[N] = h[0];
 
       __syncthreads();
 
@@ -1185,7 +1185,7 @@ namespace ocean
         #pragma unroll
         for(int i = 0; i < 2; ++i)
         {
-          cf const n = swap_in[padidx<C::PS>(N - t) - (s + i) * (T + (T >> C::PS))];
+          cf const n = swap_in[(N - t) - (s + i) * T];
 
           cf const hh = add_conj(h[s + i], n);                                // h~[k] + conj(h~[-k])
           cf const hhx = (s + i == 0) ? fma_conj(hh, n, cx) : hh;
@@ -1212,7 +1212,7 @@ namespace ocean
         int const x = t + T * s;
 
         // h~ at the negated index N - x (no wrap: element 0 also sits at index N), slot to slot a constant apart
-        cf const n = swap_in[padidx<C::PS>(N - t) - s * (T + (T >> C::PS))];
+        cf const n = swap_in[(N - t) - s * T];
 
         float const kx = wavevector(x, N, cc.scale);
         float const kinv = kinv_fast(kx, ky);
@@ -1250,11 +1250,11 @@ namespace ocean
       if constexpr (C::SEQ)
       {
         // C through the row's line, then D through the same line; C's results wait in registers for the one store per point
-        fft_lines<N, 1, C::PS, E>(reinterpret_cast<cf (&)[1][E]>(v[0]), t, line, C::LINE, midtab, w, true);
-        fft_lines<N, 1, C::PS, E>(reinterpret_cast<cf (&)[1][E]>(v[1]), t, line, C::LINE, midtab, w, true, rest);
+        fft_lines<N, 1, 1, E>(reinterpret_cast<cf (&)[1][E]>(v[0]), t, line, C::LINE, midtab, w, true);
+        fft_lines<N, 1, 1, E>(reinterpret_cast<cf (&)[1][E]>(v[1]), t, line, C::LINE, midtab, w, true, rest);
       }
       else
-        fft_lines<N, K, C::PS, E>(v, t, line, C::LINE, midtab, w, true, rest);
+        fft_lines<N, K, 1, E>(v, t, line, C::LINE, midtab, w, true, rest);
 #else
       rest();
 #endif
@@ -1354,26 +1354,21 @@ namespace ocean
 #define OCEAN_COL_FIELDS_E16 1
 #endif
     static constexpr int K = (E == 16) ? OCEAN_COL_FIELDS_E16 : OCEAN_COL_FIELDS;
-#ifndef OCEAN_COL_PAD_SHIFT
-#define OCEAN_COL_PAD_SHIFT 3
-#endif
-#ifndef OCEAN_COL_CS_EXTRA
-#define OCEAN_COL_CS_EXTRA 12
-#endif
-    static constexpr int PS = OCEAN_COL_PAD_SHIFT;
-    static constexpr int CS = LineFFT<N, PS, E>::LINE + OCEAN_COL_CS_EXTRA;   // LDS line stride (complex)
+    // LDS: the W columns of a tile element by element in one array per field (position * W + column: threads are
+    // column-fastest, so consecutive lanes touch consecutive addresses); the exchange layouts depend on W (LineFFT).  The
+    // line length does too, hence the two steps: the widest tile the threads allow, narrowed until its lines fit
     static constexpr int WRAW = ((OCEAN_COL_THREADS != 0) ? OCEAN_COL_THREADS : ((T < 128) ? 256 : (T == 128) ? 512 : 1024)) / T;    // 512^2 x 1: 8.4 us with 256 threads, 10.1 us with 512
-    static constexpr int WLDS = (int)(((size_t)160 * 1024 - (size_t)LineFFT<N, 4, E>::MIDTAB * sizeof(cf)) / ((size_t)K * CS * sizeof(cf)));   // columns whose lines fit the LDS
-    static constexpr int WFIT = WLDS >= 8 ? 8 : WLDS >= 4 ? 4 : WLDS >= 2 ? 2 : 1;
+    template<int W_> static constexpr bool fits() { return (size_t)LineFFT<N, 1, E>::MIDTAB * sizeof(cf) + (size_t)K * W_ * LineFFT<N, W_, E>::LINE * sizeof(cf) <= (size_t)160 * 1024; }
+    static constexpr int WFIT = fits<8>() ? 8 : fits<4>() ? 4 : fits<2>() ? 2 : 1;
     static constexpr int WCAP = WRAW > 8 ? 8 : (WRAW < 1 ? 1 : WRAW);
     static constexpr int W = WCAP < WFIT ? WCAP : WFIT;                 // columns per workgroup, one per thread group
     static constexpr int THREADS = W * T;
-    static constexpr int SY = N + 64 / W;                                  // height exchange: column stride (floats)
+    static constexpr int CS = LineFFT<N, W, E>::LINE;                      // elements per column line
     static constexpr int TILES = N / W;
 
-    static constexpr size_t OFF_MAIN = (size_t)LineFFT<N, 4, E>::MIDTAB * sizeof(cf);
+    static constexpr size_t OFF_MAIN = (size_t)LineFFT<N, 1, E>::MIDTAB * sizeof(cf);
     static constexpr size_t MAIN_FFT = (size_t)W * K * CS * sizeof(cf);
-    static constexpr size_t MAIN_DZ = (size_t)W * SY * sizeof(float);
+    static constexpr size_t MAIN_DZ = (size_t)W * N * sizeof(float);
     static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
 
     static_assert(N % W == 0 && 8 % W == 0, "a tile must sit inside one 8-column block");
@@ -1411,7 +1406,7 @@ namespace ocean
   {
     typedef ColCfg<N> C;
     typedef Plan<N, C::E> P;
-    typedef LineFFT<N, 4, C::E> L;
+    typedef LineFFT<N, C::W, C::E> L;
 
     constexpr int E = P::E;
     constexpr int T = P::T;
@@ -1422,8 +1417,8 @@ namespace ocean
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     cf *midtab = reinterpret_cast<cf*>(smem);
-    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [K][W][CS]
-    float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [W][SY], after the transforms
+    cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [K][CS][W]
+    float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [N][W], after the transforms
 
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
       midtab[i] = L::midtab_entry(a.tw, i);
@@ -1551,7 +1546,7 @@ namespace ocean
 
 #ifndef OCEAN_ABLATE_COLFFT
       if constexpr (K == 2)
-        fft_lines<N, 2, C::PS, E>(v, t, lines + cp * C::CS, W * C::CS, midtab, w, true, prefetch);    // lines [K][W][CS]: columns CS apart as tuned for bank spread
+        fft_lines<N, 2, W, E>(v, t, lines + cp, W * C::CS, midtab, w, true, prefetch);    // lines [K][CS][W]
       else
       {
         #pragma unroll
@@ -1564,9 +1559,9 @@ namespace ocean
             u[0][s] = v[f][s];
 
           if (f == 1)
-            fft_lines<N, 1, C::PS, E>(u, t, lines + cp * C::CS, C::CS, midtab, w, true, prefetch);
+            fft_lines<N, 1, W, E>(u, t, lines + cp, W * C::CS, midtab, w, true, prefetch);
           else
-            fft_lines<N, 1, C::PS, E>(u, t, lines + cp * C::CS, C::CS, midtab, w, true);
+            fft_lines<N, 1, W, E>(u, t, lines + cp, W * C::CS, midtab, w, true);
 
           #pragma unroll
           for(int s = 0; s < E; ++s)
@@ -1592,11 +1587,11 @@ namespace ocean
       float const sigchop = sig * cc.choppiness;
 
       // the transform lines are free after the last barrier of fft_lines: heights of this column for the y slope
-      float *own = dzmain + cp * C::SY;
+      float *own = dzmain + cp;
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
-        own[t + T * s] = v[0][s].x * sig;
+        own[(t + T * s) * W] = v[0][s].x * sig;
 
       __syncthreads();
 
@@ -1632,7 +1627,7 @@ namespace ocean
         float const dy = v[1][s].x * sigchop;
 
         float const nx = -(v[1][s].y * sig);
-        float const ny = own[(y + 1) & (N - 1)] - own[(y + N - 1) & (N - 1)];
+        float const ny = own[((y + 1) & (N - 1)) * W] - own[((y + N - 1) & (N - 1)) * W];
         float const inv = rsqrtf(nx * nx + ny * ny + nz * nz);
 
 #ifdef OCEAN_ABLATE_COLSTORE

@@ -62,3 +62,22 @@ def test_line_transform_sixteen_points_per_thread(emul, N):
         n = np.arange(N)
         want = np.exp(2j * np.pi * ((k * n) % N) / N)
         assert np.abs((out[:, 0] + 1j * out[:, 1]) - want).max() < 2e-6, k
+
+
+@pytest.mark.parametrize("E,W", [(8, 2), (8, 4), (8, 8), (16, 2), (16, 4)])
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
+def test_line_transform_interleaved_columns(emul, N, E, W):
+    # the column pass keeps its W columns element by element in one LDS array (position * W + column) and the exchange
+    # layouts depend on W (ocean_fft_core.h, "LDS layout of the exchanges"): every (radix, W) the kernels instantiate
+    rng = np.random.default_rng(N * E + W)
+    x = rng.standard_normal((N, 2)).astype(np.float32)
+    out = np.empty_like(x)
+    assert emul.emul_line_ifft_w(N, E, W, x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0
+    _check(out, x, N)
+    for k in (1, E - 1, E, (E * E + 1) % N, N // 2 + 3, N - 1):
+        x = np.zeros((N, 2), np.float32)
+        x[k, 0] = 1
+        assert emul.emul_line_ifft_w(N, E, W, x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0
+        n = np.arange(N)
+        want = np.exp(2j * np.pi * ((k * n) % N) / N)
+        assert np.abs((out[:, 0] + 1j * out[:, 1]) - want).max() < 2e-6, k
