@@ -103,7 +103,17 @@ SYMBOLS = {
     "datum_ocean_profile_begin": (I, [P, I, I]),
     "datum_ocean_profile_end": (I, [P, ctypes.POINTER(D), ctypes.POINTER(D), ctypes.POINTER(I)]),
     "datum_ocean_algorithmic_bytes": (I, [P, ctypes.POINTER(D), ctypes.POINTER(D)]),
+    "datum_ocean_abi_version": (I, []),
+    "datum_ocean_export_maps": (I, [P, I, P, ctypes.c_size_t]),
 }
+
+
+def header_abi_version():
+    """DATUM_OCEAN_ABI_VERSION of include/datum_ocean_hip.h, the contract this binding was written against."""
+    import re
+
+    text = open(os.path.join(os.path.dirname(_HERE), "include", "datum_ocean_hip.h")).read()
+    return int(re.search(r"#define\s+DATUM_OCEAN_ABI_VERSION\s+(\d+)", text).group(1))
 
 _lib = None
 
@@ -126,6 +136,17 @@ def load():
         except ImportError:
             pass
         lib = ctypes.CDLL(LIBPATH)
+        # no soname: a library built from another revision of the header (DATUM_OCEAN_HIP_LIB swaps builds freely) is refused
+        # before any call goes through a signature it may not have
+        try:
+            lib.datum_ocean_abi_version.restype = I
+            lib.datum_ocean_abi_version.argtypes = []
+            have = lib.datum_ocean_abi_version()
+        except AttributeError:
+            have = None
+        want = header_abi_version()
+        if have != want:
+            raise OSError(f"{LIBPATH} reports ABI version {have}, include/datum_ocean_hip.h is version {want}: rebuild the HIP module (`make`)")
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype = res
@@ -367,6 +388,10 @@ class Ocean:
         self._check(self.lib.datum_ocean_profile_end(self.h, ctypes.byref(row), ctypes.byref(col), ctypes.byref(n)))
         return row.value, col.value, n.value
 
+    def export_maps(self, cascade, device_ptr, nbytes):
+        """the cascade's maps as the reference's [layer][y][x][4] RGBA32F image, into DEVICE memory (datum_ocean_export_maps)"""
+        self._check(self.lib.datum_ocean_export_maps(self.h, cascade, ctypes.c_void_p(device_ptr), nbytes))
+
     def algorithmic_bytes(self):
         row, col = D(), D()
         self._check(self.lib.datum_ocean_algorithmic_bytes(self.h, ctypes.byref(row), ctypes.byref(col)))
@@ -384,7 +409,7 @@ def farm_unique_id():
 
 def map_layout(N):
     """(PW, PH, B, texel_bytes) of the device map layout at resolution N (include/datum_ocean_hip.h: datum_ocean_bind_maps):
-    patches (24-byte layout) or groups (32-byte layout) of PW x PH texels, bands of B columns."""
+    patches of PW x PH = 16 texels of 24 bytes, bands of B columns."""
     gx, gy, b, tb = I(), I(), I(), I()
     rc = load().datum_ocean_map_layout(N, ctypes.byref(gx), ctypes.byref(gy), ctypes.byref(b), ctypes.byref(tb))
     if rc != 0:
@@ -400,14 +425,10 @@ def map_block_floats(N):
 def map_layers(raw, N):
     """One cascade's DEVICE map block (map_block_floats(N) floats as the kernels lay them out, include/datum_ocean_hip.h) as
     the reference's logical image [layer][y][x][4] (.w = 0).  Works on numpy arrays and torch tensors alike.
-    24-byte layout: bands of B columns, patches of PW x PH texels, 16 x (dx, dy, dz, nx) then 16 x (ny, nz) per patch.
-    32-byte layout: groups of GX x GY texels, layer 0 of the group then layer 1 of the group (reshape / permute only)."""
+    Bands of B columns, patches of PW x PH texels, 16 x (dx, dy, dz, nx) then 16 x (ny, nz) per patch."""
     GX, GY, B, TB = map_layout(N)
+    assert TB == 24
     torchlike = hasattr(raw, "permute")
-    if TB == 32:
-        v = raw.reshape(N // B, N // GY, B // GX, 2, GY, GX, 4)   # [band][y / GY][group][layer][y % GY][x % GX][component]
-        order = (3, 1, 4, 0, 2, 5, 6)                              # -> [layer][y / GY][y % GY][band][group][x % GX][component]
-        return (v.permute(*order) if torchlike else v.transpose(*order)).reshape(2, N, N, 4)
     v = raw.reshape(N // B, N // GY, B // GX, 96)                  # [band][y / PH][patch][96 floats]
     a = v[..., :64].reshape(N // B, N // GY, B // GX, GY, GX, 4)   # (dx, dy, dz, nx) per texel
     b = v[..., 64:].reshape(N // B, N // GY, B // GX, GY, GX, 2)   # (ny, nz) per texel

@@ -59,12 +59,6 @@ struct datum_ocean_ctx
   std::vector<ImportedMemory> importedmemory;
   std::vector<hipExternalSemaphore_t> importedsemaphores;
 
-  // ocean.gen of a large mesh as two half launches that run at the same time: the second half on a stream of the module's,
-  // forked from and joined to the handle's stream by events (profiles/r04_gen_levers.txt)
-  hipStream_t genstream = nullptr;
-  hipEvent_t genfork = nullptr, genjoin = nullptr;
-  int gensplitrows = 0;               // mesh rows from which the launch is split (0: never)
-
   ocean::Farm *farm = nullptr;        // the tile farm's communicator, stream and double-buffered payload (datum_ocean_farm_init)
 
   // profiling
@@ -133,17 +127,18 @@ namespace
     if (e != hipSuccess)
       return e;
 
+    *what = "hipFuncSetAttribute(ocean_rowpass_kernel, the instantiation for phases outside [0, 2 pi), MaxDynamicSharedMemorySize)";
     e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N, H16>::LDS);
     if (e != hipSuccess)
       return e;
 
     *what = "hipFuncSetAttribute(ocean_colpass_kernel, MaxDynamicSharedMemorySize)";
-    e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
+    e = hipFuncSetAttribute(colpass_entry<N, H16>(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
     if (e != hipSuccess)
       return e;
 
     if constexpr (col_has_plain_variant<N>())
-      e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
+      e = hipFuncSetAttribute(colpass_entry<N, H16, true>(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
 
     return e;
   }
@@ -204,22 +199,19 @@ namespace
   hipError_t launch_colpass(datum_ocean_ctx *ctx, StepArgs &a, hipEvent_t *ev)
   {
     void *args[] = { &a };
-    void const *kernel = ctx->half ? reinterpret_cast<void const*>(&ocean_colpass_kernel<N, true>) : reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false>);
+    void const *kernel = ctx->half ? colpass_entry<N, true>() : colpass_entry<N, false>();
 
     if constexpr (col_has_plain_variant<N>())
     {
       if (col_plain_maps<N>(ctx->cascades))
-        kernel = ctx->half ? reinterpret_cast<void const*>(&ocean_colpass_kernel<N, true, true>) : reinterpret_cast<void const*>(&ocean_colpass_kernel<N, false, true>);
+        kernel = ctx->half ? colpass_entry<N, true, true>() : colpass_entry<N, false, true>();
     }
 
     // work items = tiles x cascades; the large grids' workgroups are persistent, one per compute unit (the LDS of a
     // 1024-thread tile fills a CU), and walk their share of the items
-#ifndef OCEAN_COL_WALK_GROUPS_PER_CU
-#define OCEAN_COL_WALK_GROUPS_PER_CU 1
-#endif
     int const items = ColCfg<N>::TILES * ctx->cascades;
     bool const walks = ctx->half ? col_walks<N, true>() : col_walks<N, false>();
-    int const groups = walks ? std::min(items, ctx->cus * OCEAN_COL_WALK_GROUPS_PER_CU) : items;
+    int const groups = walks ? std::min(items, ctx->cus) : items;
 
     return launch(kernel, dim3(groups), dim3(ColCfg<N>::THREADS), args, ColCfg<N>::LDS, ctx->stream, ev);
   }
@@ -469,12 +461,6 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
   ctx->N = resolution;
   ctx->cascades = cascades;
 
-#ifndef OCEAN_GEN_SPLIT_ROWS
-#define OCEAN_GEN_SPLIT_ROWS 0
-#endif
-  // (tools: DATUM_OCEAN_GEN_SPLIT_ROWS overrides the build's threshold)
-  ctx->gensplitrows = getenv("DATUM_OCEAN_GEN_SPLIT_ROWS") ? atoi(getenv("DATUM_OCEAN_GEN_SPLIT_ROWS")) : OCEAN_GEN_SPLIT_ROWS;
-
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1)
@@ -562,14 +548,6 @@ int datum_ocean_destroy(datum_ocean_t ctx)
 
   farm_teardown(ctx);
 
-  if (ctx->genstream)
-  {
-    (void)hipStreamSynchronize(ctx->genstream);
-    (void)hipStreamDestroy(ctx->genstream);
-    (void)hipEventDestroy(ctx->genfork);
-    (void)hipEventDestroy(ctx->genjoin);
-  }
-
   for(hipEvent_t e : ctx->events)
     (void)hipEventDestroy(e);
 
@@ -652,10 +630,10 @@ int datum_ocean_map_layout(int resolution, int *group_cols, int *group_rows, int
   if (!supported(resolution) || !group_cols || !group_rows || !band || !texel_bytes)
     return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_map_layout: bad argument");
 
-  *group_cols = MAP_COMPACT ? map_patch_cols(resolution) : map_group_cols(resolution);
-  *group_rows = MAP_COMPACT ? map_patch_rows(resolution) : map_group_rows(resolution);
+  *group_cols = map_patch_cols(resolution);
+  *group_rows = map_patch_rows(resolution);
   *band = band_cols(resolution);
-  *texel_bytes = MAP_COMPACT ? 24 : 32;
+  *texel_bytes = 24;
 
   return DATUM_OCEAN_OK;
 }
@@ -1011,29 +989,9 @@ int datum_ocean_gen(datum_ocean_t ctx, int cascade, datum_ocean_set const *set, 
   g.vertices = (float*)vertices_device;
   gen_shape(g, ctx->N, sizex, sizey);
 
-  int const groups = gen_groups(g);
-
-  if (ctx->gensplitrows > 0 && sizey >= ctx->gensplitrows && groups >= 64)
-  {
-    if (!ctx->genstream)
-    {
-      HIPCHECK(ctx, hipStreamCreateWithFlags(&ctx->genstream, hipStreamNonBlocking));
-      HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->genfork, hipEventDisableTiming));
-      HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->genjoin, hipEventDisableTiming));
-    }
-
-    // (halves in whole sets of eight workgroups: workgroup b of a launch runs on XCD b % 8, which the chunk order relies on)
-    int const first = ((groups / 2 + 7) / 8) * 8;
-
-    HIPCHECK(ctx, hipEventRecord(ctx->genfork, ctx->stream));
-    HIPCHECK(ctx, hipStreamWaitEvent(ctx->genstream, ctx->genfork, 0));
-    HIPCHECK(ctx, launch_gen_part(g, first, groups - first, ctx->genstream));
-    HIPCHECK(ctx, hipEventRecord(ctx->genjoin, ctx->genstream));
-    HIPCHECK(ctx, launch_gen_part(g, 0, first, ctx->stream));
-    HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->genjoin, 0));
-  }
-  else
-    HIPCHECK(ctx, launch_gen(g, ctx->stream));
+  // (one launch: the mesh as two half launches on two streams at once, joined by events, was measured and removed -- the fork and
+  // join cost about 20 us per call on this runtime, 36 against 16 us: profiles/r04_gen_levers.txt)
+  HIPCHECK(ctx, launch_gen(g, ctx->stream));
 
   return DATUM_OCEAN_OK;
 }
@@ -1389,7 +1347,7 @@ int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps)
 
   size_t const P = plane(ctx);
 
-  // the device layout is the module's own (ocean_kernels.hip: map_compact_a / map_index); hand out the reference's logical
+  // the device layout is the module's own (ocean_kernels.hip: map_compact_a / map_compact_b); hand out the reference's logical
   // image, [layer][y][x] RGBA32F with the .w channels zero (map.comp:79-80)
   size_t const bytes = map_cascade_bytes(ctx->N);
 
@@ -1406,25 +1364,61 @@ int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps)
   {
     for(int x = 0; x < N; ++x)
     {
-      if constexpr (MAP_COMPACT)
-      {
-        float const *a = raw.data() + map_compact_a(N, y, x) / sizeof(float);
-        float const *b = raw.data() + map_compact_b(N, y, x) / sizeof(float);
+      float const *a = raw.data() + map_compact_a(N, y, x) / sizeof(float);
+      float const *b = raw.data() + map_compact_b(N, y, x) / sizeof(float);
 
-        out[(size_t)y * N + x] = make_float4(a[0], a[1], a[2], 0.0f);
-        out[P + (size_t)y * N + x] = make_float4(a[3], b[0], b[1], 0.0f);
-      }
-      else
-      {
-        float4 const *r = reinterpret_cast<float4 const*>(raw.data());
-
-        out[(size_t)y * N + x] = r[map_index(N, y, x, 0)];
-        out[P + (size_t)y * N + x] = r[map_index(N, y, x, 1)];
-      }
+      out[(size_t)y * N + x] = make_float4(a[0], a[1], a[2], 0.0f);
+      out[P + (size_t)y * N + x] = make_float4(a[3], b[0], b[1], 0.0f);
     }
   }
 
   return DATUM_OCEAN_OK;
+}
+
+// a cascade's maps as the reference's 2-layer RGBA32F image (datum_ocean_export_maps); one thread per texel
+__global__ void __launch_bounds__(256) ocean_export_kernel(char const *maps, int N, float4 *dst)
+{
+  size_t const P = (size_t)N * N;
+
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x)
+  {
+    int const y = (int)(i / N), x = (int)(i % N);
+
+    float4 const a = *reinterpret_cast<float4 const*>(maps + map_compact_a(N, y, x));
+    float2 const b = *reinterpret_cast<float2 const*>(maps + map_compact_b(N, y, x));
+
+    dst[i] = make_float4(a.x, a.y, a.z, 0.0f);
+    dst[P + i] = make_float4(a.w, b.x, b.y, 0.0f);
+  }
+}
+
+int datum_ocean_export_maps(datum_ocean_t ctx, int cascade, void *device_dst, size_t bytes)
+{
+  if (!ctx || !device_dst)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_export_maps: null argument");
+
+  if (cascade < 0 || cascade >= ctx->cascades)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_export_maps: cascade out of range");
+
+  if (bytes < 2 * plane(ctx) * sizeof(float4))
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_export_maps: destination smaller than 2 * N * N * 16 bytes");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  size_t const P = plane(ctx);
+  int const blocks = (int)((P + 255) / 256 < 4096 ? (P + 255) / 256 : 4096);
+
+  hipLaunchKernelGGL(ocean_export_kernel, dim3(blocks), dim3(256), 0, ctx->stream,
+                     reinterpret_cast<char const*>(ctx->maps) + (size_t)cascade * map_cascade_bytes(ctx->N), ctx->N, static_cast<float4*>(device_dst));
+
+  HIPCHECK(ctx, hipGetLastError());
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_abi_version(void)
+{
+  return DATUM_OCEAN_ABI_VERSION;
 }
 
 int datum_ocean_sync(datum_ocean_t ctx)

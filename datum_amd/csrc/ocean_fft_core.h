@@ -36,11 +36,7 @@ namespace ocean
 
   OC_HD float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-#ifndef OCEAN_ASM_COMPLEX
-#define OCEAN_ASM_COMPLEX 1
-#endif
-
-#if defined(__HIP_DEVICE_COMPILE__) && OCEAN_ASM_COMPLEX
+#if defined(__HIP_DEVICE_COMPILE__)
   // Packed-fp32 complex arithmetic with the half-select / negate operand modifiers of VOP3P written out.
   // hipcc materialises the swapped or negated operand with extra v_mov / v_xor instead (4 instructions per
   // complex multiply, 3-4 per "+- i*d"); these are 2 and 1.  Same roundings as the portable forms below.
@@ -172,15 +168,8 @@ namespace ocean
   // E = 8 keeps a line transform near 50 VGPRs (E = 16: ~90) so that several lines per thread fit in registers.
   constexpr int plan_passes(int n, int e) { return n <= e ? 1 : 1 + plan_passes(n / e, e); }
 
-#ifndef OCEAN_FFT_E
-#define OCEAN_FFT_E 8
-#endif
-
   // points per thread of a line transform unless the caller chooses (the kernels do, per pass: RowCfg / ColCfg)
-#ifndef OCEAN_FFT_E16_FROM
-#define OCEAN_FFT_E16_FROM (1 << 30)      // experiments: 16 points per thread from this resolution up, in both passes
-#endif
-  constexpr int default_radix(int n) { return n == 64 ? 4 : (n >= OCEAN_FFT_E16_FROM ? 16 : OCEAN_FFT_E); }
+  constexpr int default_radix(int n) { return n == 64 ? 4 : 8; }
 
   template<int N, int E_ = default_radix(N)>
   struct Plan
@@ -215,6 +204,11 @@ namespace ocean
   // Round 4's i + (i >> 4) / i + (i >> 3) paddings put a gap inside every run of 32 consecutive elements: every
   // ds_read_b64 of the transforms took two LDS cycles per lane group instead of one (tools/lds/bank_model.py reproduces the
   // measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of 21-48 % per kernel and gives 0 for this layout from 256^2 up).
+  // The kernels are compiled with hipcc's pairing of LDS accesses switched off (OCEAN_LDS_UNPAIRED on the kernel: the
+  // "load-store-opt" target feature): two ds_read_b64 whose addresses differ by a constant otherwise become one ds_read2_b64 /
+  // ds_read2st64_b64, which the LDS serves in 16-lane groups over 32 banks at 128 bytes per clock -- half the rate of the two
+  // ds_read_b64 it replaces (measured: SQ_LDS_IDX_ACTIVE 17.1 M against 11.9 M per launch of the 4096^2 column pass, and 12 % of
+  // conflict cycles back: profiles/r05_lds_conflicts.txt).
   constexpr int lds_pad0(int e, int w) { return ((32 / e) / w) > 1 ? (32 / e) / w : 1; }
 
   //|---------------------- radix butterflies ---------------------------------
@@ -320,6 +314,80 @@ namespace ocean
     }
   };
 
+  // 16-point transform of v[r] w^r (the last pass of 4096 = 16^3): the twiddle w^r = w^a (w^4)^b of index r = a + 4b is applied in
+  // two steps, (w^4)^b in front of the 4-point transforms over b and w^a behind them -- six twiddle values live (w, w^2, w^3 and
+  // w^4, w^8, w^12) instead of the fifteen powers of a product tree (thirty registers beside the thirty-two of the values: the
+  // sequential row pass of 4096^2 spilled them), for the same 29 complex products (5 to form them + 24, against 14 + 15).
+  OC_HD void idft16_twiddled(cf (&v)[16], cf w1)
+  {
+    const float h = 0.70710678118654752440f;
+    const float c1 = 0.92387953251128675613f;   // cos(pi/8)
+    const float s1 = 0.38268343236508977173f;   // sin(pi/8)
+
+    cf const w2 = cmul(w1, w1);
+    cf const w4 = cmul(w2, w2);
+
+    {
+      cf const w8 = cmul(w4, w4);
+      cf const w12 = cmul(w8, w4);
+
+      OC_UNROLL
+      for(int a = 0; a < 4; ++a)
+      {
+        v[a + 4] = cmul(v[a + 4], w4);
+        v[a + 8] = cmul(v[a + 8], w8);
+        v[a + 12] = cmul(v[a + 12], w12);
+      }
+    }
+
+    // index = a + 4b: 4-point transforms over b for a = 0..3; slot a + 4c then holds t[a][c]
+    idft4(v[0], v[4], v[8], v[12]);
+    idft4(v[1], v[5], v[9], v[13]);
+    idft4(v[2], v[6], v[10], v[14]);
+    idft4(v[3], v[7], v[11], v[15]);
+
+    // t[a][c] *= exp(2 pi i a c / 16)
+    v[5] = cmul(v[5], cf{ c1, s1 });                                          // a=1 c=1 : w^1
+    v[9] = cf{ (v[9].x - v[9].y) * h, (v[9].x + v[9].y) * h };                // a=1 c=2 : w^2
+    v[13] = cmul(v[13], cf{ s1, c1 });                                        // a=1 c=3 : w^3
+    v[6] = cf{ (v[6].x - v[6].y) * h, (v[6].x + v[6].y) * h };                // a=2 c=1 : w^2
+    v[10] = muli(v[10]);                                                      // a=2 c=2 : w^4
+    v[14] = cf{ (-v[14].x - v[14].y) * h, (v[14].x - v[14].y) * h };          // a=2 c=3 : w^6
+    v[7] = cmul(v[7], cf{ s1, c1 });                                          // a=3 c=1 : w^3
+    v[11] = cf{ (-v[11].x - v[11].y) * h, (v[11].x - v[11].y) * h };          // a=3 c=2 : w^6
+    v[15] = cmul(v[15], cf{ -c1, -s1 });                                      // a=3 c=3 : w^9
+
+    // ... and by w^a
+    {
+      cf const w3 = cmul(w2, w1);
+
+      OC_UNROLL
+      for(int c = 0; c < 4; ++c)
+      {
+        v[1 + 4 * c] = cmul(v[1 + 4 * c], w1);
+        v[2 + 4 * c] = cmul(v[2 + 4 * c], w2);
+        v[3 + 4 * c] = cmul(v[3 + 4 * c], w3);
+      }
+    }
+
+    // 4-point transforms over a for each c; output q = c + 4d
+    cf o[16];
+    OC_UNROLL
+    for(int c = 0; c < 4; ++c)
+    {
+      cf x0 = v[4*c+0], x1 = v[4*c+1], x2 = v[4*c+2], x3 = v[4*c+3];
+      idft4(x0, x1, x2, x3);
+      o[c] = x0;
+      o[c+4] = x1;
+      o[c+8] = x2;
+      o[c+12] = x3;
+    }
+
+    OC_UNROLL
+    for(int i = 0; i < 16; ++i)
+      v[i] = o[i];
+  }
+
   // powers w^1 .. w^(R-1) of a unit twiddle by a product tree of depth <= 4
   template<int R>
   OC_HD void twiddle_powers(cf w1, cf (&w)[R])
@@ -346,6 +414,29 @@ namespace ocean
         w[8+i] = cmul(w[8], w[i]);
     }
   }
+
+  // u[q] <- sum_r u[r] w^r exp(2 pi i q r / R)
+  template<int R> struct TwiddledDft
+  {
+    static OC_HD void run(cf (&u)[R], cf w1)
+    {
+      cf p[R];
+      twiddle_powers<R>(w1, p);
+
+      OC_UNROLL
+      for(int r = 1; r < R; ++r)
+        u[r] = cmul(u[r], p[r]);
+
+      Radix<R>::run(u);
+    }
+  };
+
+  template<> struct TwiddledDft<16>
+  {
+    static OC_HD void run(cf (&u)[16], cf w1) { idft16_twiddled(u, w1); }
+  };
+
+  template<int R> OC_HD void twiddled_dft(cf (&u)[R], cf w1) { TwiddledDft<R>::run(u, w1); }
 
   //|---------------------- one line ------------------------------------------
   // tw[k] = exp(+2 pi i k / N), k < N   (built in double on the host: ocean_capi)
@@ -514,14 +605,7 @@ namespace ocean
         for(int r = 0; r < RL; ++r)
           u[r] = line[load_pos<LP>(t, m + r * (N / RL / T)) * W];     // element t + T m + r N / RL
 
-        cf p[RL];
-        twiddle_powers<RL>(w.last[m], p);
-
-        OC_UNROLL
-        for(int r = 1; r < RL; ++r)
-          u[r] = cmul(u[r], p[r]);
-
-        Radix<RL>::run(u);
+        twiddled_dft<RL>(u, w.last[m]);
 
         OC_UNROLL
         for(int q = 0; q < RL; ++q)

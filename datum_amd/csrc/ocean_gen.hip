@@ -17,7 +17,7 @@
 //   * the shading frame (gen.comp:101-120) uses v_rsq_f32 / v_exp_f32 / v_log_f32 and FMAs: errors are not amplified there;
 //   * sin / cos of the swell phase (up to 1e5..1e6 at the horizon) by the two-constant Cody-Waite step of sincos_phase;
 //   * texture(sampler2DArray) (gen.comp:113-114) is a manual bilinear REPEAT fetch from the module's own map layout
-//     (ocean_kernels.hip: map_index) in fp32 with float weights (lavapipe-style exact bilinear).  The texel index wraps
+//     (ocean_kernels.hip: map_compact_a / map_compact_b) in fp32 with float weights (lavapipe-style exact bilinear).  The texel index wraps
 //     through v_fract_f32 of coordinate / N (exact: N is a power of two), right for every float the oracle's 64-bit wrap
 //     is right for -- an int32 conversion saturates from |coordinate| = 2^31 (dist = 1e6 at wavescale < 2, N = 4096);
 //   * where a bilinear weight is exactly 0 along an axis (beyond |coordinate| = 2^23 texels, i.e. every ray above the
@@ -63,7 +63,7 @@ namespace ocean
   {
     datum_ocean_set set;
     GenFrame frame;
-    float4 const *map;     // the cascade's displacement map, map_cascade_bytes(N) bytes (ocean_kernels.hip: map_compact_a / map_index)
+    float4 const *map;     // the cascade's displacement map, map_cascade_bytes(N) bytes (ocean_kernels.hip: map_compact_a / map_compact_b)
     int N;
     int sizex;
     int sizey;
@@ -77,25 +77,13 @@ namespace ocean
 #endif
   };
 
-#ifndef OCEAN_GEN_XCD_CHUNK
-#define OCEAN_GEN_XCD_CHUNK 1        // maps beyond an XCD's L2: chunks of n tile rows are dealt to the XCDs in turn (0: never)
-#endif
-
-  // a workgroup's tile is 32 x 16 vertices, a wave owns 32 x 4 of them (a "wave tile"), a thread (x, y) and (x + 16, y)
-#ifndef OCEAN_GEN_PHASES
-#define OCEAN_GEN_PHASES 1           // sets of four rows per wave (2: software-pipelined, 32 x 32 vertices per workgroup)
-#endif
-
-#ifndef OCEAN_GEN_THREADS
-#define OCEAN_GEN_THREADS 256        // threads per workgroup (tools: 128 ... 1024; a wave owns 32 x 4 vertices whatever the size)
-#endif
+  // a workgroup's tile is 32 x 16 vertices, a wave owns 32 x 4 of them (a "wave tile"), a thread (x, y) and (x + 16, y).
+  // Measured and not kept (profiles/r03_gen_experiments.txt, r04_gen_levers.txt): 128 ... 1024 threads per workgroup, two sets of
+  // rows per wave as a software pipeline, forced occupancies through unused LDS.
   constexpr int GEN_TILE_X = 32;
-  constexpr int GEN_THREADS = OCEAN_GEN_THREADS;
-  constexpr int GEN_TILE_Y = 4 * OCEAN_GEN_PHASES * (GEN_THREADS / 64);
-#ifndef OCEAN_GEN_EXTRA_LDS
-#define OCEAN_GEN_EXTRA_LDS 0         // tools/: bytes of unused LDS per workgroup (limits the workgroups per CU: 160 KB / (24 KB + extra))
-#endif
-  constexpr size_t GEN_LDS = (size_t)GEN_THREADS * 2 * 3 * sizeof(float4) + OCEAN_GEN_EXTRA_LDS;
+  constexpr int GEN_THREADS = 256;
+  constexpr int GEN_TILE_Y = 4 * (GEN_THREADS / 64);
+  constexpr size_t GEN_LDS = (size_t)GEN_THREADS * 2 * 3 * sizeof(float4);
 
   inline GenFrame make_gen_frame(datum_ocean_set const &p, int N, int sizex, int sizey)
   {
@@ -249,125 +237,72 @@ namespace ocean
   }
 
   // BYTE offset of a texel column's / row's part of the map layout (ocean_kernels.hip); the two add up to the texel's
-  // displacement: part A of its patch, (dx, dy, dz, nx), in the compact layout -- whose part B, (ny, nz), lies at
-  // A + 256 - bcolumn(i) - brow(j) -- or its float4 of layer 0 in the 32-byte layout (layer 1 is MAP_GROUP float4 on).
+  // displacement: part A of its patch, (dx, dy, dz, nx) -- whose part B, (ny, nz), lies at A + 256 - bcolumn(i) - brow(j).
   //   PLAIN   N <= 1024: whole rows
   //   BANDED  2048 and 4096: bands of band_cols(N) columns
-  //   PATCHED (32-byte layout only) 4096: bands, groups of 2 x 2 texels
-  enum GenLayout { GEN_PLAIN = 0, GEN_BANDED = 1, GEN_PATCHED = 2 };
+  enum GenLayout { GEN_PLAIN = 0, GEN_BANDED = 1 };
 
   template<int LAYOUT> struct TexelIndex
   {
     int ln, lb, bmask;
-    int lpw, lph;            // compact: log2 of the patch's columns and rows
+    int lpw, lph;            // log2 of the patch's columns and rows
 
     __device__ __forceinline__ TexelIndex(int N) : ln(31 - __builtin_clz(N)), lb(31 - __builtin_clz(band_cols(N))), bmask(band_cols(N) - 1),
                                                    lpw(31 - __builtin_clz(map_patch_cols(N))), lph(31 - __builtin_clz(map_patch_rows(N))) { }
 
     __device__ __forceinline__ int column(int i) const
     {
-      if constexpr (MAP_COMPACT)
-      {
-        int const inband = ((i & bmask) >> lpw) * MAP_PATCH_BYTES + ((i & ((1 << lpw) - 1)) << 4);
+      int const inband = ((i & bmask) >> lpw) * MAP_PATCH_BYTES + ((i & ((1 << lpw) - 1)) << 4);
 
-        if constexpr (LAYOUT == GEN_PLAIN)
-          return inband;
-        else
-          return (i >> lb) * (3 << (3 + ln + lb)) + inband;           // 24 N B bytes per band
-      }
-      else if constexpr (LAYOUT == GEN_PLAIN)
-        return (i + (i & ~3)) * 16;
-      else if constexpr (LAYOUT == GEN_BANDED)
-        return (((i >> lb) << (1 + ln + lb)) + ((i & bmask) & ~3) * 2 + (i & 3)) * 16;
+      if constexpr (LAYOUT == GEN_PLAIN)
+        return inband;
       else
-        return (((i >> lb) << (1 + ln + lb)) + ((i & bmask) & ~1) * 4 + (i & 1)) * 16;
+        return (i >> lb) * (3 << (3 + ln + lb)) + inband;           // 24 N B bytes per band
     }
 
     __device__ __forceinline__ int row(int j) const
     {
-      if constexpr (MAP_COMPACT)
-        return (j >> lph) * (3 << (7 + lb - lpw)) + ((j & ((1 << lph) - 1)) << (4 + lpw));     // 384 B / PW bytes per patch row
-      else if constexpr (LAYOUT == GEN_PATCHED)
-        return (((j >> 1) << (2 + lb)) + ((j & 1) << 1)) * 16;
-      else
-        return (j << (1 + lb)) * 16;
+      return (j >> lph) * (3 << (7 + lb - lpw)) + ((j & ((1 << lph) - 1)) << (4 + lpw));     // 384 B / PW bytes per patch row
     }
 
-    // compact: 8 * (the texel's index in its patch), column and row part
+    // 8 * (the texel's index in its patch), column and row part
     __device__ __forceinline__ int bcolumn(int i) const { return (i & ((1 << lpw) - 1)) << 3; }
     __device__ __forceinline__ int brow(int j) const { return (j & ((1 << lph) - 1)) << (3 + lpw); }
   };
-
-  static_assert(MAP_GROUP == 4, "a group is one 128-byte line: 8 float4");
-
-  // what a corner's second fetch brings: (ny, nz) in the compact layout, the whole normal texel otherwise
-  typedef std::conditional<MAP_COMPACT, float2, float4>::type GenNormalFetch;
 
   //|---------------------- the kernel ------------------------------------------
   // (One function, local arrays: with the three stages as functions over structs, or inside a loop over tiles, hipcc keeps
   // 134-154 registers instead of 86 and spills -- measured 17.7 against 16.3 us; a persistent loop, 3 or 4 workgroups
   // per CU: 17.1 / 18.1 us; a 1024-thread workgroup per CU sampling a 64^2 map from LDS: 24.5 us.  profiles/r03_gen_experiments.txt)
 
-  // cache policy of the vertex stream's stores (50 MB per 1024 x 1024 mesh, written once, read by the graphics queue):
-  // 0 plain, 1 sc0, 2 nt, 16 sc1, 17 sc0 sc1 (written through), 18 sc1 nt ...  measured: profiles/r04_gen_levers.txt
-#ifndef OCEAN_GEN_STORE_AUX
-#define OCEAN_GEN_STORE_AUX 2         // nt: 26.1 -> 25.5 us from 1024^2 maps, nothing lost from 64^2 maps
-#endif
-
-  // (the policies other than nt exist as inline asm only, for the tools' A/B builds.  An asm store needs the wait states of
-  // "VALU write of a VGPR that holds the data of a VMEM store wider than 64 bits" written out -- hipcc's hazard recognizer does not
-  // look into inline asm, and without them 3 in 10 000 floats of a 1024 x 1024 mesh came out as the NEXT store's address
-  // arithmetic: tools/dbg/gen_compare.py.  The nt form is the compiler's own builtin.)
+  // The vertex stream (50 MB per 1024 x 1024 mesh, written once, read by the graphics queue) is stored non-temporally: 26.1 ->
+  // 25.5 us from 1024^2 maps, nothing lost from 64^2 maps; the other policies measured in profiles/r04_gen_levers.txt.  (The
+  // compiler's own builtin: as inline asm the store needs the wait states of "VALU write of a VGPR that holds the data of a VMEM
+  // store wider than 64 bits" written out -- hipcc's hazard recognizer does not look into inline asm, and without them 3 in 10 000
+  // floats of a 1024 x 1024 mesh came out as the NEXT store's address arithmetic: tools/dbg/gen_compare.py.)
   __device__ __forceinline__ void store_vertex_float4(float4 *at, float4 v)
   {
     typedef float f4_ __attribute__((ext_vector_type(4)));
 
     f4_ const d = { v.x, v.y, v.z, v.w };
 
-    if constexpr (OCEAN_GEN_STORE_AUX == 0)
-      *at = v;
-    else if constexpr (OCEAN_GEN_STORE_AUX == 2)
-      __builtin_nontemporal_store(d, reinterpret_cast<f4_*>(at));
-    else if constexpr (OCEAN_GEN_STORE_AUX == 1)
-      asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" :: "v"(at), "v"(d) : "memory");
-    else if constexpr (OCEAN_GEN_STORE_AUX == 16)
-      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(at), "v"(d) : "memory");
-    else if constexpr (OCEAN_GEN_STORE_AUX == 17)
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(at), "v"(d) : "memory");
-    else if constexpr (OCEAN_GEN_STORE_AUX == 18)
-      asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" :: "v"(at), "v"(d) : "memory");
-    else
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" :: "v"(at), "v"(d) : "memory");
+    __builtin_nontemporal_store(d, reinterpret_cast<f4_*>(at));
   }
 
-  template<bool COMPACT> struct NormalFetch;
-
-  template<> struct NormalFetch<true>
+  // a corner's second fetch, (ny, nz); the normal's x rides in the first one's .w
+  struct GenNormal
   {
-    static __device__ __forceinline__ float2 load(__amdgpu_buffer_rsrc_t rmap, int, int compact_offset) { return buf_load_f32x2(rmap, compact_offset, 0); }
-    static __device__ __forceinline__ float2 ablated() { return make_float2(0.1f, 0.9f); }
+    static __device__ __forceinline__ float2 load(__amdgpu_buffer_rsrc_t rmap, int compact_offset) { return buf_load_f32x2(rmap, compact_offset, 0); }
     static __device__ __forceinline__ float x(float4 a, float2) { return a.w; }
     static __device__ __forceinline__ float y(float4, float2 b) { return b.x; }
     static __device__ __forceinline__ float z(float4, float2 b) { return b.y; }
   };
 
-  template<> struct NormalFetch<false>
-  {
-    static __device__ __forceinline__ float4 load(__amdgpu_buffer_rsrc_t rmap, int displacement_offset, int) { return buf_load_f32x4_aux<0>(rmap, displacement_offset + MAP_GROUP * 16, 0); }
-    static __device__ __forceinline__ float4 ablated() { return make_float4(0.0f, 0.1f, 0.9f, 0.0f); }
-    static __device__ __forceinline__ float x(float4, float4 b) { return b.x; }
-    static __device__ __forceinline__ float y(float4, float4 b) { return b.y; }
-    static __device__ __forceinline__ float z(float4, float4 b) { return b.z; }
-  };
+  typedef float2 GenNormalFetch;
 
-  typedef NormalFetch<MAP_COMPACT> GenNormal;
-
-#ifndef OCEAN_GEN_WAVES_PER_SIMD
-#define OCEAN_GEN_WAVES_PER_SIMD 5   // the register budget the kernel is compiled for (96): 101 without it, one wave per SIMD fewer
-#endif
-
+  // (compiled for five waves per SIMD, 96 registers: 101 without the bound, one wave per SIMD fewer)
   template<int LAYOUT>
-  __attribute__((amdgpu_waves_per_eu(OCEAN_GEN_WAVES_PER_SIMD, OCEAN_GEN_WAVES_PER_SIMD)))
+  __attribute__((amdgpu_waves_per_eu(5, 5)))
   __global__ void __launch_bounds__(GEN_THREADS) ocean_gen_kernel(GenArgs g)
   {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -377,7 +312,7 @@ namespace ocean
 #endif
     OCEAN_STAMP(0);
 
-    constexpr int PH = OCEAN_GEN_PHASES;
+    constexpr int PH = 1;       // sets of four rows per wave (two, software-pipelined, measured slower)
 
     datum_ocean_set const &p = g.set;
     GenFrame const &f = g.frame;
@@ -508,13 +443,10 @@ namespace ocean
 
         o00[ph][i] = r0 + c0; o10[ph][i] = wantx ? r0 + c1 : -256; o01[ph][i] = wanty ? r1 + c0 : -256; o11[ph][i] = (wantx && wanty) ? r1 + c1 : -256;
 
-        if constexpr (MAP_COMPACT)
-        {
-          int const bc0 = texel.bcolumn(i0), bc1 = texel.bcolumn(i1);
-          int const br0 = 256 - texel.brow(j0), br1 = 256 - texel.brow(j1);
+        int const bc0 = texel.bcolumn(i0), bc1 = texel.bcolumn(i1);
+        int const br0 = 256 - texel.brow(j0), br1 = 256 - texel.brow(j1);
 
-          q00[ph][i] = o00[ph][i] + br0 - bc0; q10[ph][i] = wantx ? o10[ph][i] + br0 - bc1 : -256; q01[ph][i] = wanty ? o01[ph][i] + br1 - bc0 : -256; q11[ph][i] = (wantx && wanty) ? o11[ph][i] + br1 - bc1 : -256;
-        }
+        q00[ph][i] = o00[ph][i] + br0 - bc0; q10[ph][i] = wantx ? o10[ph][i] + br0 - bc1 : -256; q01[ph][i] = wanty ? o01[ph][i] + br1 - bc0 : -256; q11[ph][i] = (wantx && wanty) ? o11[ph][i] + br1 - bc1 : -256;
 
         near[ph] = near[ph] || wantx || wanty;
       }
@@ -528,13 +460,8 @@ namespace ocean
 
       // (a corner's normal sits in the 128-byte line of its displacement: fetched right behind it, it finds the line in L1 --
       // eight displacement fetches of 64 lanes later the line may have left the cache again)
-#ifdef OCEAN_GEN_ABLATE_LOADS      // timing-only builds (tools/): no map fetches
-      #define OCEAN_GEN_FETCH_A(C) a##C[ph][i] = make_float4(0.01f * (float)(o##C[ph][i] & 7), 0.02f, 0.03f * (float)(o##C[ph][i] & 3), 0.0f)
-      #define OCEAN_GEN_FETCH_B(C) b##C[ph][i] = GenNormal::ablated()
-#else
       #define OCEAN_GEN_FETCH_A(C) a##C[ph][i] = buf_load_f32x4_aux<0>(rmap, o##C[ph][i], 0)
-      #define OCEAN_GEN_FETCH_B(C) b##C[ph][i] = GenNormal::load(rmap, o##C[ph][i], q##C[ph][i])
-#endif
+      #define OCEAN_GEN_FETCH_B(C) b##C[ph][i] = GenNormal::load(rmap, q##C[ph][i])
 
       if (shaded[ph])
       {
@@ -660,20 +587,10 @@ namespace ocean
         int const j = 64 * k + lane;
         int const r = j / 96, c = j % 96;
 
-#ifdef OCEAN_GEN_ABLATE_STORES     // timing-only builds: the values stay live, nothing is written
-        if (mine[j].w == 123456.789f)
-#endif
         if (c < rowlen && y0 + r < g.sizey)
           store_vertex_float4(out + (unsigned)(r * g.sizex * 3 + c), mine[j]);
       }
 
-      if (PH > 1)
-      {
-        // the staging area is written again by the next set
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
     }
 
     OCEAN_STAMP_WHERE();
@@ -682,7 +599,7 @@ namespace ocean
 
   inline GenLayout gen_layout(int N)
   {
-    return (!MAP_COMPACT && map_group_rows(N) == 2) ? GEN_PATCHED : (band_cols(N) != N) ? GEN_BANDED : GEN_PLAIN;
+    return (band_cols(N) != N) ? GEN_BANDED : GEN_PLAIN;
   }
 
   // everything but the set header, the map and the vertex buffer
@@ -694,7 +611,7 @@ namespace ocean
     g.sizey = sizey;
     g.tilesx = (sizex + GEN_TILE_X - 1) / GEN_TILE_X;
     g.tiles = g.tilesx * ((sizey + GEN_TILE_Y - 1) / GEN_TILE_Y);
-    g.chunk = (map_cascade_bytes(N) > ((size_t)4 << 20)) ? OCEAN_GEN_XCD_CHUNK * g.tilesx : 0;
+    g.chunk = (map_cascade_bytes(N) > ((size_t)4 << 20)) ? g.tilesx : 0;       // maps beyond an XCD's L2: chunks of one tile row are dealt to the XCDs in turn
     g.block0 = 0;
   }
 
@@ -703,8 +620,7 @@ namespace ocean
     switch(gen_layout(N))
     {
       case GEN_PLAIN: return reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_PLAIN>);
-      case GEN_BANDED: return reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_BANDED>);
-      default: return reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_PATCHED>);
+      default: return reinterpret_cast<void const*>(&ocean_gen_kernel<GEN_BANDED>);
     }
   }
 
@@ -719,9 +635,6 @@ namespace ocean
   {
     void *args[] = { &g };
     void const *kernel = gen_kernel_for(g.N);
-
-    if (GEN_LDS > 64 * 1024)       // (tools/ builds only)
-      (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEN_LDS);
 
     g.block0 = first;
 

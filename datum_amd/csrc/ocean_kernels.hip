@@ -17,7 +17,7 @@
 //
 // Work spectrum layout (private to these kernels): per cascade, 8 x 8 blocks of 16-byte values (C, D),
 // [y/8][x/8][y%8][x%8]: a row of a block is one 128-byte line; a column-pass wave reads whole blocks.  The largest grids
-// keep the columns one XCD works on at a time contiguous ([x/B][...]: blocked_at, band_cols), for the maps too (map_index).
+// keep the columns one XCD works on at a time contiguous ([x/B][...]: blocked_at, band_cols), for the maps too (map_compact_patch).
 // From 2048^2 up the column pass's workgroups are persistent and walk their tiles, at 4096^2 the row pass's too.
 //
 // Built with -ffp-contract=off: products and sums are rounded as written (the phase state is
@@ -61,7 +61,7 @@ namespace ocean
     float2 const *h0;    // [cascade][N*N]       OceanSet::h0
     float *phase;        // [cascade][N*N]       OceanSet::phase
     void *spec;          // [cascade][N*N]       work spectrum (replaces Spectrum::h, hx, hy), blocked layout: cd, or ch (fp16 variant)
-    float4 *maps;        // [cascade][2*N*N]     displacementmap, 2 layers RGBA32F, texel groups interleaved (map_index)
+    float4 *maps;        // [cascade][2*N*N]     displacementmap, 2 layers, 24-byte texels in patches (map_compact_a / map_compact_b)
     cf const *tw;        // [N]                  exp(+2 pi i k / N)
     float const *omega;  // [cascade][(N/2+1)^2] dispersion(k) by (|m - N/2|, |n - N/2|)
     int ndt;
@@ -84,27 +84,15 @@ namespace ocean
   #define OCEAN_WAIT_LOADS() do { } while(0)
 #endif
 
-#ifndef OCEAN_SPEC_BLOCK_ROWS
-#define OCEAN_SPEC_BLOCK_ROWS 8
-#endif
-#ifndef OCEAN_SPEC_BLOCK_COLS
-#define OCEAN_SPEC_BLOCK_COLS 8
-#endif
-  constexpr int SBR = OCEAN_SPEC_BLOCK_ROWS, SBC = OCEAN_SPEC_BLOCK_COLS;
+  constexpr int SBR = 8, SBC = 8;
 
   // Bands (large grids): the columns one XCD's column-pass workgroups work on at the same time are made contiguous in
   // memory -- [x / B][rows][x % B] -- for the work spectrum and for the maps alike, so that what is read and written
   // concurrently is a dense region instead of 2 KB pieces of rows 128 KB apart (4096^2).  B = band_cols(N), 0 = whole rows.
   // measured (profiles/r02_large_grids.txt): 4096^2 B = 64 (32 CUs x 2-column tiles): column pass 240 -> 226 us, with the
   // fp16-stored spectrum 202 -> 164 us; 2048^2 x 4 B = 128 (32 CUs x 4-column tiles): 181 -> 167 us; B = 512 at 4096^2: 270 us.
-  // With the maps in 2 x 2 patches at 4096^2 (map_index): B = 64 184-195 us, B = 128 176-183 us, B = 256 192 us, B = 512 / none 220 us
-#ifndef OCEAN_BAND_COLS_4096
-#define OCEAN_BAND_COLS_4096 128
-#endif
-#ifndef OCEAN_BAND_COLS_2048
-#define OCEAN_BAND_COLS_2048 128
-#endif
-  __host__ __device__ __forceinline__ constexpr int band_cols(int N) { return (N >= 4096) ? OCEAN_BAND_COLS_4096 : (N >= 2048) ? OCEAN_BAND_COLS_2048 : N; }
+  // With the maps in 2 x 2 patches at 4096^2 (round 3's layout): B = 64 184-195 us, B = 128 176-183 us, B = 256 192 us, B = 512 / none 220 us
+  __host__ __device__ __forceinline__ constexpr int band_cols(int N) { return (N >= 2048) ? 128 : N; }
 
   // element index of grid point (y, x) in the blocked work spectrum: per band, blocks of SBR rows x SBC columns, row-major inside
   __host__ __device__ __forceinline__ constexpr size_t blocked_at(int N, int y, int x)
@@ -120,66 +108,27 @@ namespace ocean
     return blocked_at(N, y, x);
   }
 
-  // Displacement map layout (private to this module: in the reference the map is a VK_IMAGE_TILING_OPTIMAL 2-layer
-  // image whose only reader is ocean.gen's sampler, ocean.cpp:706, gen.comp:113-114).  Per cascade, groups of four
-  // texels: 64 bytes of layer 0 (displacement) of the four, then 64 bytes of layer 1 (normal) of the same four, so that
-  // one 128-byte line holds both layers of four neighbouring texels: a bilinear corner of ocean.gen finds its
-  // displacement and its normal in one cache line instead of two lines 16 N^2 bytes apart.
-  // A group is GX x GY texels (map_group_cols / map_group_rows):
-  //   4 x 1 up to 2048^2 -- four neighbours of a row: the column pass's four-column tiles write whole lines;
-  //   2 x 2 at 4096^2    -- a patch of two rows: there the tiles are TWO columns wide (LDS), and with 4 x 1 groups their
-  //                         stores were 32-byte pieces of lines that the neighbouring tile completes (3.3 TB/s); four lanes
-  //                         = two rows of two columns now fill a 64-byte half line per store instruction, the pair of
-  //                         instructions a line (memory skeleton of the pass, tools/dbg/band.hip: 193 -> 159 us).
-#ifndef OCEAN_MAP_GROUP
-#define OCEAN_MAP_GROUP 4
-#endif
-#ifndef OCEAN_MAP_PATCH_FROM
-#define OCEAN_MAP_PATCH_FROM 4096
-#endif
-  constexpr int MAP_GROUP = OCEAN_MAP_GROUP;      // texels per group = float4 from a group's layer 0 to its layer 1
-
-  __host__ __device__ __forceinline__ constexpr int map_group_rows(int N) { return (MAP_GROUP == 4 && N >= OCEAN_MAP_PATCH_FROM) ? 2 : 1; }
-  __host__ __device__ __forceinline__ constexpr int map_group_cols(int N) { return MAP_GROUP / map_group_rows(N); }
-
-  // float4 index of texel (x, y) of `layer` (bands as for the spectrum: [x / B][y / GY][groups of the band's rows]):
-  __host__ __device__ __forceinline__ constexpr size_t map_index(int N, int y, int x, int layer)
-  {
-    int const B = band_cols(N);
-    int const GX = map_group_cols(N), GY = map_group_rows(N);
-
-    return (size_t)(x / B) * 2 * N * B + ((size_t)(y / GY) * (B / GX) + (x % B) / GX) * (2 * MAP_GROUP) + layer * MAP_GROUP + (y % GY) * GX + (x % GX);
-  }
-
-  // float4 per row of a band: from a texel to the same column map_group_rows(N) * k rows on it is k * map_group_rows(N) * map_row_pitch(N)
-  __host__ __device__ __forceinline__ constexpr int map_row_pitch(int N) { return 2 * band_cols(N); }
-
-  // COMPACT layout (round 4, OCEAN_MAP_COMPACT): 24 bytes per texel instead of 32 -- the two RGBA32F layers' .w channels are
+  // Displacement map layout (private to this module: in the reference the map is a VK_IMAGE_TILING_OPTIMAL 2-layer image whose
+  // only reader is ocean.gen's sampler, ocean.cpp:706, gen.comp:113-114; datum_ocean_read_maps / datum_ocean_export_maps hand out
+  // the logical [layer][y][x] RGBA32F image).
+  // 24 bytes per texel instead of 32 -- the two RGBA32F layers' .w channels are
   // constant zero (map.comp:79-80) and nothing reads them (gen.comp:113-114 takes .xyz), yet they were a quarter of what the
   // write-bound column pass stores.  Per cascade, bands as above; inside a band PATCHES of PW x PH = 16 texels, patch rows
   // one after the other; a patch is 384 bytes = three 128-byte lines:
   //     part A, 256 bytes: texel j = (y % PH) * PW + x % PW  ->  float4 (dx, dy, dz, nx)   at 16 j
   //     part B, 128 bytes: texel j                            ->  float2 (ny, nz)           at 256 + 8 j
-  // PW = the column pass's tile width at that resolution (8 up to 256^2, 4 up to 2048^2, 2 at 4096^2), so that the 16 texels of
+  // PW = the column pass's tile width at that resolution (8 up to 256^2, 2 at 512^2, 4 at 1024^2 and 2048^2, 2 at 4096^2), so that the 16 texels of
   // a patch are 16 neighbouring lanes of a column-pass wave: one 16-byte and one 8-byte store instruction per thread and slot
   // write two whole lines and one whole line per patch -- no lane trades, no partial lines.  For ocean.gen a 4 x 4 patch holds
   // the four corners of a bilinear fetch more often than a 4 x 1 group did.
-#ifndef OCEAN_MAP_COMPACT
-#define OCEAN_MAP_COMPACT 1
-#endif
-  constexpr bool MAP_COMPACT = OCEAN_MAP_COMPACT != 0;
-
   constexpr int MAP_PATCH = 16;                   // texels per patch
   constexpr int MAP_PATCH_BYTES = 384;
 
-#ifndef OCEAN_MAP_PATCH_COLS_4096
-#define OCEAN_MAP_PATCH_COLS_4096 2        // (4 with a column pass of 16 points per thread at 4096^2: four-column tiles)
-#endif
-  __host__ __device__ __forceinline__ constexpr int map_patch_cols(int N) { return N <= 256 ? 8 : (N <= 2048 ? 4 : OCEAN_MAP_PATCH_COLS_4096); }     // == ColCfg<N>::W (asserted there)
+  __host__ __device__ __forceinline__ constexpr int map_patch_cols(int N) { return N <= 256 ? 8 : (N == 512 ? 2 : (N <= 2048 ? 4 : 2)); }     // == ColCfg<N>::W (asserted there)
   __host__ __device__ __forceinline__ constexpr int map_patch_rows(int N) { return MAP_PATCH / map_patch_cols(N); }
 
   // bytes of one cascade's maps
-  __host__ __device__ __forceinline__ constexpr size_t map_cascade_bytes(int N) { return (size_t)N * N * (MAP_COMPACT ? 24 : 32); }
+  __host__ __device__ __forceinline__ constexpr size_t map_cascade_bytes(int N) { return (size_t)N * N * 24; }
 
   // byte offset of texel (x, y)'s part A inside its cascade's block; part B is map_compact_b(...)
   __host__ __device__ __forceinline__ constexpr size_t map_compact_patch(int N, int y, int x)
@@ -198,14 +147,10 @@ namespace ocean
   // bytes from a texel's patch to the patch of the same column k * PH rows on
   __host__ __device__ __forceinline__ constexpr int map_compact_patchrow_bytes(int N) { return (band_cols(N) / map_patch_cols(N)) * MAP_PATCH_BYTES; }
 
-  // (dx, dy, dz) of a texel whatever the layout (pack kernel)
-  template<bool COMPACT = MAP_COMPACT>
+  // (dx, dy, dz, nx) of a texel (pack kernel)
   __host__ __device__ __forceinline__ float4 map_displacement(float4 const *maps, int N, int y, int x)
   {
-    if constexpr (COMPACT)
-      return *reinterpret_cast<float4 const*>(reinterpret_cast<char const*>(maps) + map_compact_a(N, y, x));
-    else
-      return maps[map_index(N, y, x, 0)];
+    return *reinterpret_cast<float4 const*>(reinterpret_cast<char const*>(maps) + map_compact_a(N, y, x));
   }
 
   //|---------------------- buffer addressing ----------------------------------
@@ -267,29 +212,13 @@ namespace ocean
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, voffset + soffset, 0, AUX);
   }
 
-// measured at 1024^2 x 4: map stores written through (sc0 sc1) leave the XCD's L2 to the spectrum lines that neighbouring
-// tiles share: column pass 36.7 -> 35.1 us; nt on the same stores 44.5 us, nt on the spectrum loads 44.4 us
-#ifndef OCEAN_MAP_STORE_AUX
-#define OCEAN_MAP_STORE_AUX 17
-#endif
-// (row pass with both of its store streams written through: 29.4 -> 28.4 us; either one alone: no change)
-#ifndef OCEAN_PHASE_STORE_AUX
-#define OCEAN_PHASE_STORE_AUX 17
-#endif
-#ifndef OCEAN_SPEC_STORE_AUX
-#define OCEAN_SPEC_STORE_AUX 17
-#endif
-#ifndef OCEAN_SPEC_LOAD_AUX
-#define OCEAN_SPEC_LOAD_AUX 0
-#endif
-// (row pass: the phase is read once and overwritten, h0 is read twice -- as a pair's own row and as its neighbour's mirror row;
-//  policies other than the default measured in profiles/r04_load_policy_sweep.txt)
-#ifndef OCEAN_PHASE_LOAD_AUX
-#define OCEAN_PHASE_LOAD_AUX 0
-#endif
-#ifndef OCEAN_H0_LOAD_AUX
-#define OCEAN_H0_LOAD_AUX 0
-#endif
+  // cache policies (the aux operand of the buffer instructions: 0 plain, 1 sc0, 2 nt, 16 sc1, 17 sc0 sc1 = written through), measured:
+  //   map stores written through leave the XCD's L2 to the spectrum lines that neighbouring tiles share: column pass 36.7 -> 35.1 us at
+  //   1024^2 x 4 (nt on the same stores 44.5 us, nt on the spectrum loads 44.4 us); the row pass with both of its store streams written
+  //   through: 29.4 -> 28.4 us (either one alone: no change); loads: nothing gains, nt on h0 loses 6 us (the mirror read no longer
+  //   finds the row in L2): profiles/r04_store_policy_sweep.txt, r04_load_policy_sweep.txt.  At 4096^2, and from two cascades of 2048^2
+  //   on, the maps are far beyond the Infinity Cache and written-through map stores cost 2x: plain there (MAP_STORE_AUX_BIG).
+  constexpr int MAP_STORE_AUX = 17, MAP_STORE_AUX_BIG = 0, PHASE_STORE_AUX = 17, SPEC_STORE_AUX = 17;
 
   //|---------------------- update_ocean --------------------------------------
 
@@ -405,7 +334,7 @@ namespace ocean
     *cos_out = ((q + 1) & 2) ? -c : c;
   }
 
-  // The row pass's sin / cos of ONE phase: the hardware's v_sin_f32 / v_cos_f32 of phase / 2 pi (OCEAN_ROW_HW_SINCOS; what a
+  // The row pass's sin / cos of ONE phase: the hardware's v_sin_f32 / v_cos_f32 of phase / 2 pi (what a
   // Vulkan driver makes of the shader's sin() and cos(), sim.comp:61-62, on this GPU: |error| <= 4.8e-7 for phases in [0, 2 pi),
   // tools/dbg/hwsin.hip) or sincos_phase above
   template<bool WILD> __device__ __forceinline__ void sincos_row(float x, float *sin_out, float *cos_out);
@@ -461,13 +390,6 @@ namespace ocean
   // slots are taken in pairs (s, s + 1).  With -ffp-contract=off every product and sum is rounded as the scalar form rounds
   // it (the phase state stays bit-identical to update_ocean's).  A real factor that belongs to ONE slot of a pair enters
   // the complex operations through the half-select modifiers (broadcast of one half), not through a splat.
-#ifndef OCEAN_ROW_PACKED
-#define OCEAN_ROW_PACKED 1
-#endif
-#ifndef OCEAN_ROW_HW_SINCOS
-#define OCEAN_ROW_HW_SINCOS 1        // v_sin_f32 / v_cos_f32 of phase / 2 pi instead of the reduction + polynomials (accuracy: tools/dbg/hwsin.hip)
-#endif
-
   typedef float f2_ __attribute__((ext_vector_type(2)));
 
   __device__ __forceinline__ f2_ pfma2(f2_ a, f2_ b, f2_ c) { return __builtin_elementwise_fma(a, b, c); }
@@ -505,7 +427,6 @@ namespace ocean
   template<bool WILD>
   __device__ __forceinline__ void sincos_phase_pair(f2_ x, f2_ &sn, f2_ &cs)
   {
-#if OCEAN_ROW_HW_SINCOS
     if constexpr (WILD)
     {
       sincos_phase_pair_poly(x, sn, cs);
@@ -522,15 +443,11 @@ namespace ocean
     // its hazard recognizer does not look into (measured: RMSE 1e-3..6e-2 at the resolutions where the scheduler happened to
     // put a product right behind a v_cos_f32).  The results pass through this statement, so every reader comes after it.
     asm volatile("s_nop 1" : "+v"(sn), "+v"(cs));
-#else
-    sincos_phase_pair_poly(x, sn, cs);
-#endif
   }
 
   template<bool WILD>
   __device__ __forceinline__ void sincos_row(float x, float *sin_out, float *cos_out)
   {
-#if OCEAN_ROW_HW_SINCOS
     if constexpr (WILD)
     {
       sincos_phase(x, sin_out, cos_out);
@@ -545,12 +462,9 @@ namespace ocean
 
     *sin_out = sn;
     *cos_out = cs;
-#else
-    sincos_phase(x, sin_out, cos_out);
-#endif
   }
 
-#if defined(__HIP_DEVICE_COMPILE__) && OCEAN_ASM_COMPLEX
+#if defined(__HIP_DEVICE_COMPILE__)
   // a + c[H] * b
   template<int H> __device__ __forceinline__ cf fma_real_h(cf a, cf b, f2_ c)
   {
@@ -595,9 +509,6 @@ namespace ocean
   template<int H> __host__ __device__ __forceinline__ cf scale_real_h(cf a, f2_ c) { return scale_real(a, c[H]); }
 #endif
 
-  // timing-only ablations (never defined in a shipped build): -DOCEAN_ABLATE_ROWLOAD / ROWSTORE / ROWFFT /
-  // COLLOAD / COLSTORE / COLFFT remove one ingredient while keeping the rest alive
-
   //|---------------------- per-thread twiddles of a line transform ------------
 
   template<int N, int E_> struct LineTw
@@ -609,6 +520,13 @@ namespace ocean
   //|---------------------- line FFTs with workgroup barriers ------------------
   // K independent lines per thread go through the exchange phases together, so the number of barriers per
   // workgroup does not grow with K (one line per barrier phase is what the reference's per-field loop does).
+
+  // the step kernels keep their LDS accesses unpaired (ocean_fft_core.h, "LDS layout of the exchanges")
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OCEAN_LDS_UNPAIRED __attribute__((target("no-load-store-opt")))
+#else
+#define OCEAN_LDS_UNPAIRED
+#endif
 
   struct NoHook { __device__ __forceinline__ void operator()() const { } };
 
@@ -747,76 +665,43 @@ namespace ocean
   // is -pi N scale at both): the general form  F_H = (F[k] + conj(F[-k])) / 2  is evaluated with the sign that
   // applies, so the result equals the reference's three transforms to rounding (tests/test_oracle_pins.py).
 
-#ifndef OCEAN_ROW_WALK_FROM
-#define OCEAN_ROW_WALK_FROM 4096
-#endif
-#ifndef OCEAN_ROW_REST_IN_HOOK
-#define OCEAN_ROW_REST_IN_HOOK 1
-#endif
-#ifndef OCEAN_ROW_EARLY
-#define OCEAN_ROW_EARLY 3          // walking row pass: the parts of the next pair's inputs requested BEFORE the transforms (see request): h0 and its mirror row
-#endif
-
   // 2048^2 (round 4, profiles/r04_structure_variants.txt): the 1024^2 column pass's recipe in the row pass -- 16 points per thread (2048 = 16 x 16 x 8:
   // three passes, two exchanges instead of four and three), the two fields one after the other through one LDS line per row (35 KB
   // per 256-thread pair), three workgroups per CU at 144 registers, no spill: row pass 31.2 -> 28.6 us (x 1), 118.9 -> 112.2 us (x 4),
   // with the fp16-stored spectrum 29.1 -> 25.7 us.  Not at 1024^2 (28.9 against 25.2 us), not with four per CU (128 registers, 72 bytes
   // of spill: 33.8 us), not without the sequential fields (65 KB, two 4-wave workgroups per CU: 31.2 us).
-#ifndef OCEAN_ROW_E16_FROM
-#define OCEAN_ROW_E16_FROM 2048      // row pass: 16 points per thread from this resolution up (half the threads per row pair)
-#endif
-#ifndef OCEAN_ROW_SEQ_FROM
-#define OCEAN_ROW_SEQ_FROM 2048      // row pass: the two packed fields one after the other through ONE LDS line per row (half the LDS)
-#endif
-#ifndef OCEAN_ROW_SEQ_FP32
-#define OCEAN_ROW_SEQ_FP32 0         // ... with the fp32-stored spectrum too, at every such resolution (4096^2: spills, 155 against 132 us walking)
-#endif
-#ifndef OCEAN_ROW_SEQ_FP32_AT
-#define OCEAN_ROW_SEQ_FP32_AT 2048   // ... at this resolution
-#endif
-
   template<int N, bool H16 = false>
   struct RowCfg
   {
-#ifndef OCEAN_ROW_E4_AT
-#define OCEAN_ROW_E4_AT 0            // experiments: 4 points per thread at this resolution too (twice the threads per row pair; small grids are latency-bound)
-#endif
-    static constexpr int E = (N >= OCEAN_ROW_E16_FROM) ? 16 : (N == OCEAN_ROW_E4_AT ? 4 : default_radix(N));
+    static constexpr int E = (N >= 2048) ? 16 : default_radix(N);         // points per thread
     static constexpr int T = Plan<N, E>::T;
-#ifndef OCEAN_ROW_PAIR_THREADS
-#define OCEAN_ROW_PAIR_THREADS 128   // threads of a row-pass workgroup when one row pair needs fewer (small grids are
-#endif                               // latency-bound: more, smaller workgroups; 512^2 x 1: 9.2 us against 9.9 us with 256)
-    static constexpr int PAIRS = (2 * T >= OCEAN_ROW_PAIR_THREADS) ? 1 : OCEAN_ROW_PAIR_THREADS / (2 * T);   // row pairs per workgroup
+    // threads of a row-pass workgroup when one row pair needs fewer (small grids are latency-bound: more, smaller workgroups;
+    // 512^2 x 1: 9.2 us with 128 against 9.9 us with 256)
+    static constexpr int PAIR_THREADS = 128;
+    static constexpr int PAIRS = (2 * T >= PAIR_THREADS) ? 1 : PAIR_THREADS / (2 * T);   // row pairs per workgroup
     static constexpr int THREADS = 2 * T * PAIRS;
-    // one field per set of barrier phases, the other waits in registers -- with the fp16-stored spectrum only: as halves C's
-    // results wait in 16 registers, as floats in 32 and the kernel spills (4096^2 fp32: 155 against 132 us)
-    static constexpr bool SEQ = (N >= OCEAN_ROW_SEQ_FROM) && (H16 || OCEAN_ROW_SEQ_FP32 || N == OCEAN_ROW_SEQ_FP32_AT);
+    // SEQ: the two packed fields one after the other through ONE LDS line per row (half the LDS), the other waits in registers -- at
+    // 2048^2, and at 4096^2 with the fp16-stored spectrum only: as halves C's results wait in 16 registers, as floats in 32 and the
+    // kernel spills (4096^2 fp32: 155 against 132 us walking)
+    static constexpr bool SEQ = (N >= 2048) && (H16 || N == 2048);
     static constexpr int K = SEQ ? 1 : 2;                                  // LDS lines per row
     // the prologue two slots per instruction -- not in the sequential form, whose registers are full (4096^2 fp16: 56 bytes of
     // spill and 134 us packed against 28 bytes and 124-128 us: profiles/r04_rowpass_packed.txt)
-#ifndef OCEAN_ROW_PACKED_SEQ_AT
-#define OCEAN_ROW_PACKED_SEQ_AT 0      // experiments: ... but in the sequential form at this resolution
-#endif
-    static constexpr bool PACKED = (OCEAN_ROW_PACKED != 0) && (!SEQ || N == OCEAN_ROW_PACKED_SEQ_AT);
+    static constexpr bool PACKED = !SEQ;
     static constexpr int LINE = LineFFT<N, 1, E>::LINE;                    // >= N + 2: element 0 once more at index N (the Hermitian swap)
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
-    static constexpr bool WALK = (N >= OCEAN_ROW_WALK_FROM) && PAIRS == 1 && !SEQ;       // see ocean_rowpass_kernel
+    static constexpr bool WALK = (N >= 4096) && PAIRS == 1 && !SEQ;       // see ocean_rowpass_kernel
     static constexpr int STASH = 1 + LineTwiddles<N, E>::NMIDREG + Plan<N, E>::M;             // per-thread twiddles the walking variant keeps in LDS between pairs
     static constexpr size_t LDS = ((size_t)LineFFT<N, 1, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)STASH * T : 0)) * sizeof(cf);
 
     static constexpr int FIT = (int)(((size_t)160 * 1024) / LDS);                              // workgroups per CU the LDS allows
-#ifndef OCEAN_ROW_WALK_PER_CU
-#define OCEAN_ROW_WALK_PER_CU 2
-#endif
-    static constexpr int PER_CU = (FIT < OCEAN_ROW_WALK_PER_CU) ? (FIT < 1 ? 1 : FIT) : OCEAN_ROW_WALK_PER_CU;   // persistent workgroups per compute unit (walking)
-#ifndef OCEAN_ROW_SEQ_MAX_PER_CU
-#define OCEAN_ROW_SEQ_MAX_PER_CU 4
-#endif
-#ifndef OCEAN_ROW_SEQ_MAX_PER_CU_2048
-#define OCEAN_ROW_SEQ_MAX_PER_CU_2048 3
-#endif
-    static constexpr int SEQ_PER_CU = (N == 2048) ? OCEAN_ROW_SEQ_MAX_PER_CU_2048 : OCEAN_ROW_SEQ_MAX_PER_CU;     // sequential form: workgroups per CU the registers are budgeted for
+    static constexpr int PER_CU = (FIT < 2) ? (FIT < 1 ? 1 : FIT) : 2;                         // persistent workgroups per compute unit (walking)
+    static constexpr int SEQ_PER_CU = (N == 2048) ? 3 : 4;                                     // sequential form: workgroups per CU the registers are budgeted for
     static constexpr int MIN_WAVES = WALK ? (THREADS / 64) * PER_CU / 4 : (SEQ ? ((THREADS / 64) * (FIT > SEQ_PER_CU ? SEQ_PER_CU : FIT) + 3) / 4 : 1);   // per SIMD, for __launch_bounds__
+
+    // walking form: the parts of the next pair's inputs requested BEFORE the transforms (see request): h0 and its mirror row;
+    // the rest between the last exchange and the last pass
+    static constexpr int EARLY = 3;
 
     static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
   };
@@ -862,12 +747,12 @@ namespace ocean
     }
   }
 
-  // One group of row pairs per workgroup -- except at N >= OCEAN_ROW_WALK_FROM, where one 1024-thread workgroup fills a CU
+  // One group of row pairs per workgroup -- except at 4096^2 with the fp32 spectrum (RowCfg::WALK), where one 1024-thread workgroup fills a CU
   // (LDS) and a pair's phases ran one after the other with 4-5 us between two workgroups on a CU (store drain + launch):
   // there the workgroups are persistent and walk their pairs.  The next pair's inputs are requested BEFORE the current
   // pair's stores, so that the wait for them counts past those stores and the stores drain under the next pair's
   // arithmetic -- and as early as the 128 registers a thread may have there allow: h0 and its mirror row (32 registers,
-  // OCEAN_ROW_EARLY) before the transforms, phase and dispersion (16) between the last exchange and the last pass, where
+  // RowCfg::EARLY) before the transforms, phase and dispersion (16) between the last exchange and the last pass, where
   // the value registers are free (fft_lines' before_last hook).  4096^2: 178 us one pair per workgroup, 161-168 us walking
   // with everything requested behind the transforms, 135-137 us so; all 48 before the transforms spill (191 us), h0 +
   // mirror + phase fits and is slower (146-150 us): profiles/r02_4096_second_pass.txt.  What it took to keep hipcc from
@@ -880,7 +765,7 @@ namespace ocean
   // WILD: a phase may lie outside [0, 2 pi) (sincos_phase_pair); its own instantiation rather than a branch in the kernel: the
   // registers of the second path cost the 4096^2 fp16 form 12 more bytes of spill and 6 us (profiles/r04_rowpass_packed.txt)
   template<int N, bool H16, bool WILD = false>
-  __global__ void __launch_bounds__((RowCfg<N, H16>::THREADS), (RowCfg<N, H16>::MIN_WAVES)) ocean_rowpass_kernel(StepArgs a)
+  __global__ void OCEAN_LDS_UNPAIRED __launch_bounds__((RowCfg<N, H16>::THREADS), (RowCfg<N, H16>::MIN_WAVES)) ocean_rowpass_kernel(StepArgs a)
   {
     typedef RowCfg<N, H16> C;
     typedef Plan<N, C::E> P;
@@ -949,34 +834,26 @@ namespace ocean
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
-#ifdef OCEAN_ABLATE_ROWLOAD
-        in.ph[s] = 0.001f * (float)(t + T * s);
-        in.hk[s] = make_float2(0.01f * (float)((t + s) & 15), 0.02f);
-        in.hm[s] = make_float2(0.03f, 0.01f * (float)(y & 15));
-#else
         if (parts & 4)
-          in.ph[s] = buf_load_f32<OCEAN_PHASE_LOAD_AUX>(rphase, e0 * 4, T * s * 4);
+          in.ph[s] = buf_load_f32(rphase, e0 * 4, T * s * 4);
         if (parts & 1)
-          in.hk[s] = buf_load_f32x2<OCEAN_H0_LOAD_AUX>(rh0, e0 * 8, T * s * 8);
+          in.hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
         if (parts & 2)
           in.hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
-#endif
       }
 
       if (advance && (parts & 8))
       {
+        // dispersion_lookup (ocean_omega_kernel's quadrant table) through the buffer path.  |x - N/2| of slot s is N/2 - t - T s in the
+        // lower half of the slots and t + T (s - E/2) in the upper: two per-thread offsets and compile-time steps, not one address
+        // register per slot
+        int const i = abs(y - N / 2);
+        int const lower = (i * (N / 2 + 1) + N / 2 - t - T * (E / 2 - 1)) * 4;       // slot E/2 - 1, the lowest address of the lower half
+        int const upper = (i * (N / 2 + 1) + t) * 4;                                 // slot E/2
+
         #pragma unroll
         for(int s = 0; s < E; ++s)
-#ifdef OCEAN_ABLATE_ROWLOAD
-          in.om[s] = 1.0f + 0.001f * (float)s;
-#else
-        {
-          // dispersion_lookup (ocean_omega_kernel's quadrant table) through the buffer path
-          int const j = abs(t + T * s - N / 2), i = abs(y - N / 2);
-
-          in.om[s] = buf_load_f32(romega, (i * (N / 2 + 1) + j) * 4, 0);
-        }
-#endif
+          in.om[s] = (s < E / 2) ? buf_load_f32(romega, lower, T * (E / 2 - 1 - s) * 4) : buf_load_f32(romega, upper, T * (s - E / 2) * 4);
       }
     };
 
@@ -1021,6 +898,8 @@ namespace ocean
 
       if constexpr (WALK)
       {
+        // (an opaque copy of the thread's index: everything derived from its coordinates belongs to the pair, or hipcc hoists it out
+        // of the loop into registers that the pair's arithmetic needs; the thread's twiddles wait in the LDS between pairs)
         int tid = (int)threadIdx.x;
 
         asm volatile("" : "+v"(tid));
@@ -1101,10 +980,7 @@ namespace ocean
         #pragma unroll
         for(int s = 0; s < E; ++s)
         {
-#ifdef OCEAN_ABLATE_ROWSTORE
-          if (ph[s] == 123456.789f)
-#endif
-          buf_store_f32_aux<OCEAN_PHASE_STORE_AUX>(ph[s], rphase, (y * N + t) * 4, T * s * 4);
+          buf_store_f32_aux<PHASE_STORE_AUX>(ph[s], rphase, (y * N + t) * 4, T * s * 4);
         }
       }
 
@@ -1236,17 +1112,16 @@ namespace ocean
 
       OCEAN_STAMP(3);
 
-      if constexpr (WALK && OCEAN_ROW_EARLY != 0)
-        request(next, t, in, OCEAN_ROW_EARLY);
+      if constexpr (WALK)
+        request(next, t, in, C::EARLY);
 
       // the rest between the last exchange and the last pass, where the value registers are free
       auto rest = [&]()
       {
-        if constexpr (WALK && OCEAN_ROW_EARLY != 15 && OCEAN_ROW_REST_IN_HOOK)
-          request(next, t, in, 15 & ~OCEAN_ROW_EARLY);
+        if constexpr (WALK)
+          request(next, t, in, 15 & ~C::EARLY);
       };
 
-#ifndef OCEAN_ABLATE_ROWFFT
       if constexpr (C::SEQ)
       {
         // C through the row's line, then D through the same line; C's results wait in registers for the one store per point
@@ -1255,48 +1130,22 @@ namespace ocean
       }
       else
         fft_lines<N, K, 1, E>(v, t, line, C::LINE, midtab, w, true, rest);
-#else
-      rest();
-#endif
-
-      if constexpr (WALK && OCEAN_ROW_EARLY != 15 && !OCEAN_ROW_REST_IN_HOOK)
-        request(next, t, in, 15 & ~OCEAN_ROW_EARLY);
 
       OCEAN_STAMP(4);
-
-#ifdef OCEAN_ROW_STORE_PRIO      // experiment: the waves that are about to store and retire go first
-      __builtin_amdgcn_s_setprio(OCEAN_ROW_STORE_PRIO);
-#endif
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
-#ifdef OCEAN_ABLATE_ROWSTORE
-        if (v[0][s].x == 123456.789f)
-#endif
         if constexpr (H16)
         {
           // round to nearest even; the host picks specscale so that no row sum can overflow (ocean_capi: spectrum_scale)
           half4_ const hv = { (_Float16)(v[0][s].x * cc.specscale), (_Float16)(v[0][s].y * cc.specscale), (_Float16)(v[1][s].x * cc.specscale), (_Float16)(v[1][s].y * cc.specscale) };
 
-          buf_store_cf_aux<OCEAN_SPEC_STORE_AUX>(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
+          buf_store_cf_aux<SPEC_STORE_AUX>(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
         }
         else
         {
-#ifdef OCEAN_ABLATE_SPLIT_CD    // timing only (the column pass reads garbage): what the row pass would gain from 12 instead of 16 bytes per point
-          // between the passes -- C of every row and D of one row of each pair, each as a dense array of 8-byte values in blocks of
-          // 8 rows x 16 columns (whole 128-byte lines per block row)
-          {
-            int const cidx = (((y >> 3) * (N / 16) + (t >> 4)) << 7) + ((y & 7) << 4) + (t & 15);
-
-            buf_store_cf_aux<OCEAN_SPEC_STORE_AUX>(v[0][s], rspec, cidx * 8, (T / 16) * 128 * s * 8);
-
-            if (half == 0)
-              buf_store_cf_aux<OCEAN_SPEC_STORE_AUX>(v[1][s], rspec, N * N * 8 + cidx * 8, (T / 16) * 128 * s * 8);
-          }
-#else
-          buf_store_f32x4_aux<OCEAN_SPEC_STORE_AUX>(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
-#endif
+          buf_store_f32x4_aux<SPEC_STORE_AUX>(make_float4(v[0][s].x, v[0][s].y, v[1][s].x, v[1][s].y), rspec, (int)blocked<N>(y, t) * 16, DBO * s * 16);
         }
       }
 
@@ -1333,31 +1182,16 @@ namespace ocean
     // with the two fields one after the other (half the LDS: 37 KB, three workgroups per CU at 148 registers): column pass
     // 34.2 -> 31.3 us, 65.8 k -> 69 k grids/s (tools/ab_4096.sh, profiles/r02_col_radix16.txt).  Not elsewhere: 512^2 8.2
     // against 5.5 us, 2048^2 x 4 168 against 160 us, 4096^2 170-187 (erratic) against 174-175 us.
-#ifndef OCEAN_COL_E16_FROM
-#define OCEAN_COL_E16_FROM 1024
-#endif
-#ifndef OCEAN_COL_E16_TO
-#define OCEAN_COL_E16_TO 2048
-#endif
-#ifndef OCEAN_COL_E4_AT
-#define OCEAN_COL_E4_AT 0
-#endif
-    static constexpr int E = (N >= OCEAN_COL_E16_FROM && N < OCEAN_COL_E16_TO) ? 16 : (N == OCEAN_COL_E4_AT ? 4 : default_radix(N));
+    static constexpr int E = (N == 1024) ? 16 : default_radix(N);         // points per thread
     static constexpr int T = Plan<N, E>::T;
-#ifndef OCEAN_COL_THREADS
-#define OCEAN_COL_THREADS 0        // 0 = by size
-#endif
-#ifndef OCEAN_COL_FIELDS
-#define OCEAN_COL_FIELDS 2         // fields per barrier phase: 2 (together) or 1 (one after the other, half the LDS)
-#endif
-#ifndef OCEAN_COL_FIELDS_E16
-#define OCEAN_COL_FIELDS_E16 1
-#endif
-    static constexpr int K = (E == 16) ? OCEAN_COL_FIELDS_E16 : OCEAN_COL_FIELDS;
+    static constexpr int K = (E == 16) ? 1 : 2;                            // fields per set of barrier phases: 2 = together, 1 = one after the other (half the LDS)
     // LDS: the W columns of a tile element by element in one array per field (position * W + column: threads are
     // column-fastest, so consecutive lanes touch consecutive addresses); the exchange layouts depend on W (LineFFT).  The
     // line length does too, hence the two steps: the widest tile the threads allow, narrowed until its lines fit
-    static constexpr int WRAW = ((OCEAN_COL_THREADS != 0) ? OCEAN_COL_THREADS : ((T < 128) ? 256 : (T == 128) ? 512 : 1024)) / T;    // 512^2 x 1: 8.4 us with 256 threads, 10.1 us with 512
+    // 512^2: two-column tiles of 128 threads -- a single cascade is then 256 workgroups, one per CU, instead of 128 on half the chip
+    // (round 5: column pass 3.69 -> 3.39 us inside the kernel, step 11.9 -> 11.6 us; ocean.gen from 512^2 maps 18.1 -> 16.6 us with
+    // the 2 x 8 patches that come with it; four cascades: no change.  profiles/r05_sizes.txt)
+    static constexpr int WRAW = (N == 512 ? 128 : ((T < 128) ? 256 : (T == 128) ? 512 : 1024)) / T;
     template<int W_> static constexpr bool fits() { return (size_t)LineFFT<N, 1, E>::MIDTAB * sizeof(cf) + (size_t)K * W_ * LineFFT<N, W_, E>::LINE * sizeof(cf) <= (size_t)160 * 1024; }
     static constexpr int WFIT = fits<8>() ? 8 : fits<4>() ? 4 : fits<2>() ? 2 : 1;
     static constexpr int WCAP = WRAW > 8 ? 8 : (WRAW < 1 ? 1 : WRAW);
@@ -1372,7 +1206,7 @@ namespace ocean
     static constexpr size_t LDS = OFF_MAIN + (MAIN_FFT > MAIN_DZ ? MAIN_FFT : MAIN_DZ);
 
     static_assert(N % W == 0 && 8 % W == 0, "a tile must sit inside one 8-column block");
-    static_assert(!MAP_COMPACT || (W == map_patch_cols(N) && T % map_patch_rows(N) == 0), "a patch of the compact map layout is 16 neighbouring lanes of a column-pass wave");
+    static_assert(W == map_patch_cols(N) && T % map_patch_rows(N) == 0, "a patch of the map layout is 16 neighbouring lanes of a column-pass wave");
     static_assert(OFF_MAIN % 16 == 0, "LDS carve must stay 16-byte aligned");
   };
 
@@ -1382,16 +1216,9 @@ namespace ocean
   // transforms + 72 us of loads + 110 us of stores = the 247 us measured).  There the workgroups are persistent: each
   // walks a run of tiles, requests the next tile's values before transforming the current one and lets the current
   // tile's stores drain under the next tile's transforms.
-#ifndef OCEAN_COL_MINBLOCKS
-#define OCEAN_COL_MINBLOCKS 1
-#endif
-#ifndef OCEAN_COL_WALK_FROM
-#define OCEAN_COL_WALK_FROM 2048
-#endif
-
   // measured (profiles/r02_large_grids.txt), with the band layouts: 2048^2 x 4 182 -> 168 us, 4096^2 219 -> 210 us; without
   // them 208 -> 187 us and 248 -> 259 us (not every step of this was a gain on its own)
-  template<int N, bool H16> constexpr bool col_walks() { return N >= OCEAN_COL_WALK_FROM; }
+  template<int N, bool H16> constexpr bool col_walks() { return N >= 2048; }
 
   // PLAIN: the maps' stores are not written through (col_plain_maps: the sizes at which several cascades' maps are far
   // beyond the Infinity Cache although one cascade's are not; the policy is part of the instruction, hence a template flag)
@@ -1401,8 +1228,8 @@ namespace ocean
   // 79 -> 75 us, x 4: 167.5 -> 160.8 us; x 1: 36.5 -> 37 us; 1024^2 x 8 / x 16: no difference) -- profiles/r02_4096_second_pass.txt
   template<int N> inline bool col_plain_maps(int cascades) { return col_has_plain_variant<N>() && cascades >= 2; }
 
-  template<int N, bool H16, bool PLAIN = false>
-  __global__ void __launch_bounds__(ColCfg<N>::THREADS, OCEAN_COL_MINBLOCKS) ocean_colpass_kernel(StepArgs a)
+  template<int N, bool H16, bool PLAIN>
+  __device__ __forceinline__ void colpass_body(StepArgs const &a)
   {
     typedef ColCfg<N> C;
     typedef Plan<N, C::E> P;
@@ -1454,17 +1281,10 @@ namespace ocean
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
-#ifdef OCEAN_ABLATE_COLLOAD
-        if constexpr (H16)
-          q[s] = cf{ 0.01f * (float)((t + s) & 31), 0.02f * (float)s };
-        else
-          q[s] = make_float4(0.01f * (float)((t + s) & 31), 0.02f * (float)s, 0.03f, 0.01f * (float)cp);
-#else
         if constexpr (H16)
           q[s] = buf_load_cf(rspec, (int)blocked<N>(t, x) * 8, DBI * s * 8);
         else
-          q[s] = buf_load_f32x4_aux<OCEAN_SPEC_LOAD_AUX>(rspec, (int)blocked<N>(t, x) * 16, DBI * s * 16);
-#endif
+          q[s] = buf_load_f32x4_aux<0>(rspec, (int)blocked<N>(t, x) * 16, DBI * s * 16);
       }
     };
 
@@ -1535,16 +1355,13 @@ namespace ocean
 
       auto prefetch = [&]()
       {
-#ifndef OCEAN_COL_NO_PREFETCH
         if constexpr (WALK)
         {
           if (more)
             request(next, t, cp, q);
         }
-#endif
       };
 
-#ifndef OCEAN_ABLATE_COLFFT
       if constexpr (K == 2)
         fft_lines<N, 2, W, E>(v, t, lines + cp, W * C::CS, midtab, w, true, prefetch);    // lines [K][CS][W]
       else
@@ -1568,9 +1385,6 @@ namespace ocean
             v[f][s] = u[0][s];
         }
       }
-#else
-      prefetch();
-#endif
 
       OCEAN_STAMP(2);
 
@@ -1599,22 +1413,15 @@ namespace ocean
 
       float const nz = cc.nz;
 
-#ifdef OCEAN_COL_STORE_PRIO      // experiment: as in the row pass
-      __builtin_amdgcn_s_setprio(OCEAN_COL_STORE_PRIO);
-#endif
-
-      int const o0 = MAP_COMPACT ? 0 : (int)map_index(N, t, x, 0) * 16;   // byte offset of this thread's first texel (layer 0; layer 1 is 16 MAP_GROUP bytes on)
-
-      // line stores (four-column tiles): this lane's 16 bytes of row (t & ~1) and of row (t | 1): the even quad writes
-      // the displacement half of either line, the odd quad the normal half
-      int const olo = MAP_COMPACT ? 0 : (int)map_index(N, t & ~1, x, t & 1) * 16;
-      int const ohi = MAP_COMPACT ? 0 : (int)map_index(N, t | 1, x, t & 1) * 16;
-
-      // compact layout: this thread's texel of its patch, part A and part B; slot to slot T / PH patch rows on
-      int const oa = MAP_COMPACT ? (int)map_compact_a(N, t, x) : 0;
-      int const ob = MAP_COMPACT ? (int)map_compact_b(N, t, x) : 0;
+      // this thread's texel of its patch, part A and part B; slot to slot T / PH patch rows on
+      int const oa = (int)map_compact_a(N, t, x);
+      int const ob = (int)map_compact_b(N, t, x);
 
       constexpr int SLOTBYTES = (T / map_patch_rows(N)) * map_compact_patchrow_bytes(N);
+
+      // (at 4096^2, where the 403 MB of maps are far beyond the Infinity Cache, writing through costs 2x: 487-525 us against
+      // 250-260 us in round 2's layouts)
+      constexpr int MAPAUX = (N <= 2048 && !PLAIN) ? MAP_STORE_AUX : MAP_STORE_AUX_BIG;
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
@@ -1630,53 +1437,9 @@ namespace ocean
         float const ny = own[((y + 1) & (N - 1)) * W] - own[((y + N - 1) & (N - 1)) * W];
         float const inv = rsqrtf(nx * nx + ny * ny + nz * nz);
 
-#ifdef OCEAN_ABLATE_COLSTORE
-        if (nx * inv + dx + dy == 123456.789f)
-#endif
-        {
-          // (at 4096^2, where the 537 MB of maps are far beyond the Infinity Cache, writing through costs 2x: 487-525 us
-          // against 250-260 us, with 32-byte runs of 2-column tiles and with 64-byte runs of two columns per thread alike)
-#ifndef OCEAN_MAP_STORE_AUX_BIG
-#define OCEAN_MAP_STORE_AUX_BIG 0
-#endif
-          constexpr int MAPAUX = (N <= 2048 && !PLAIN) ? OCEAN_MAP_STORE_AUX : OCEAN_MAP_STORE_AUX_BIG;
-
-#ifndef OCEAN_COL_LINE_STORES
-#define OCEAN_COL_LINE_STORES 1
-#endif
-          if constexpr (MAP_COMPACT)
-          {
-            // 16 neighbouring lanes = one patch: 256 contiguous bytes (two lines) by the first instruction, 128 (one line) by the second
-            buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, nx * inv), rmaps, oa, SLOTBYTES * s);
-            buf_store_cf_aux<MAPAUX>(cf{ ny * inv, nz * inv }, rmaps, ob, SLOTBYTES * s);
-          }
-          else if constexpr (OCEAN_COL_LINE_STORES && W == 4 && MAP_GROUP == 4 && map_group_rows(N) == 1)
-          {
-            // Lanes 4 k .. 4 k + 3 of a wave hold the four texels of row t, the next four lanes those of row t + 1.  The
-            // two rows trade halves (DPP row shifts by four lanes), so that ONE store instruction writes a row's whole
-            // 128-byte line -- 64 bytes of displacement from the even quad, 64 bytes of normal from the odd quad -- instead of
-            // two instructions writing one half each (written through, half lines cost 24 us per 134 MB against 19-20 us).
-            float const dsp[3] = { dx, dy, dz }, nrm[3] = { nx * inv, ny * inv, nz * inv };
-            float lo[3], hi[3];
-
-            #pragma unroll
-            for(int k = 0; k < 3; ++k)
-            {
-              // row of the even quad: its own displacement | the normal of the even quad, fetched by the odd quad from four lanes down
-              lo[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, dsp[k]), __builtin_bit_cast(int, nrm[k]), 0x114, 0xF, 0xA, false));
-              // row of the odd quad: the displacement of the odd quad, fetched by the even quad from four lanes up | its own normal
-              hi[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, nrm[k]), __builtin_bit_cast(int, dsp[k]), 0x104, 0xF, 0x5, false));
-            }
-
-            buf_store_f32x4_aux<MAPAUX>(make_float4(lo[0], lo[1], lo[2], 0.0f), rmaps, olo, T * s * map_row_pitch(N) * 16);
-            buf_store_f32x4_aux<MAPAUX>(make_float4(hi[0], hi[1], hi[2], 0.0f), rmaps, ohi, T * s * map_row_pitch(N) * 16);
-          }
-          else
-          {
-            buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, 0.0f), rmaps, o0, T * s * map_row_pitch(N) * 16);
-            buf_store_f32x4_aux<MAPAUX>(make_float4(nx * inv, ny * inv, nz * inv, 0.0f), rmaps, o0, T * s * map_row_pitch(N) * 16 + MAP_GROUP * 16);
-          }
-        }
+        // 16 neighbouring lanes = one patch: 256 contiguous bytes (two lines) by the first instruction, 128 (one line) by the second
+        buf_store_f32x4_aux<MAPAUX>(make_float4(dx, dy, dz, nx * inv), rmaps, oa, SLOTBYTES * s);
+        buf_store_cf_aux<MAPAUX>(cf{ ny * inv, nz * inv }, rmaps, ob, SLOTBYTES * s);
       }
 
       OCEAN_STAMP(4);
@@ -1705,13 +1468,40 @@ namespace ocean
         // the heights of the previous tile were read from the LDS this tile's first pass writes
         __syncthreads();
 
-#ifdef OCEAN_COL_NO_PREFETCH
-        request(item, t_, cp_, q);
-#endif
-
         one_tile(item, q, item + stride < items, item + stride);
       }
     }
+  }
+
+  template<int N, bool H16, bool PLAIN = false>
+  __global__ void OCEAN_LDS_UNPAIRED __launch_bounds__(ColCfg<N>::THREADS) ocean_colpass_kernel(StepArgs a)
+  {
+    colpass_body<N, H16, PLAIN>(a);
+  }
+
+  // The same kernel with hipcc's pairing of LDS accesses left on.  1024^2 only: there the column pass (16 points per thread, 37 KB of
+  // LDS per 256-thread tile) is worth more with FOUR tiles per CU than with 64-bank reads, and the register allocation fits four
+  // (124 registers) only in the paired form (unpaired: 138, or 128 with 44 bytes of spill): 24.8-25.1 against 25.7-26.2 us at
+  // 1024^2 x 4, 20.7 against 23.5 us with the fp16-stored spectrum (profiles/r05_lds_conflicts.txt).
+  template<int N> constexpr bool col_pairs_lds() { return N == 1024; }
+
+  namespace paired
+  {
+    template<int N, bool H16, bool PLAIN = false>
+    __global__ void __launch_bounds__(ColCfg<N>::THREADS) ocean_colpass_kernel(StepArgs a)
+    {
+      colpass_body<N, H16, PLAIN>(a);
+    }
+  }
+
+  // the column-pass kernel the module launches at this resolution
+  template<int N, bool H16, bool PLAIN = false>
+  inline void const *colpass_entry()
+  {
+    if constexpr (col_pairs_lds<N>())
+      return reinterpret_cast<void const*>(&paired::ocean_colpass_kernel<N, H16, PLAIN>);
+    else
+      return reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H16, PLAIN>);
   }
 
   // blocked packed spectrum -> two row-major complex planes (datum_ocean_debug_rowpass)

@@ -713,6 +713,11 @@ void initialise_ocean_context(DatumPlatform::PlatformInterface &platform, OceanC
   // prepare_ocean_context, so only the device is recorded
   (void)queueindex;
 
+  // the shared object carries no soname: refuse a libdatum_ocean_hip.so built from another revision of the header (its error codes,
+  // signatures or the layout of bound map buffers may differ) before anything is called through it
+  if (datum_ocean_abi_version() != DATUM_OCEAN_ABI_VERSION)
+    throw runtime_error("HIP ocean module: libdatum_ocean_hip.so reports ABI version " + to_string(datum_ocean_abi_version()) + ", this host library was built against " + to_string(DATUM_OCEAN_ABI_VERSION));
+
   context.device = platform.hipdevice;
 }
 

@@ -161,6 +161,13 @@ int main(int argc, char **argv)
   if (world < 1 || world > 64)
     return 2;
 
+  // the module carries no soname: refuse a libdatum_ocean_hip.so of another revision of the header (touches no GPU)
+  if (datum_ocean_abi_version() != DATUM_OCEAN_ABI_VERSION)
+  {
+    fprintf(stderr, "libdatum_ocean_hip.so reports ABI version %d, built against %d\n", datum_ocean_abi_version(), DATUM_OCEAN_ABI_VERSION);
+    return 2;
+  }
+
   // nothing below touches a GPU in this process: the ranks are children, started before any HIP call
   int fromzero[2];
   std::vector<int> tochild(2 * world, -1);

@@ -32,6 +32,16 @@ extern "C" {
 
 #define DATUM_OCEAN_MAX_CASCADES 16
 
+/* Version of THIS header's contract: bumped whenever a signature, an error code's value or the device layout of a bound map
+ * buffer changes (the shared object carries no soname).  A consumer compares it with what the library it loaded reports before its
+ * first call -- datum_amd/capi.py, the C++ host shim (initialise_ocean_context) and both examples do -- so that a stale
+ * libdatum_ocean_hip.so is refused instead of misread.
+ *   3  round 3: ENOTREADY = +1, datum_ocean_map_layout with four arguments, 32-byte texels
+ *   4  round 4: ENOTREADY = -5, datum_ocean_map_layout gained texel_bytes, 24-byte texels in bound map buffers, farm entry points
+ *   5  round 5: datum_ocean_abi_version, datum_ocean_export_maps */
+#define DATUM_OCEAN_ABI_VERSION 5
+int datum_ocean_abi_version(void);
+
 enum
 {
   DATUM_OCEAN_OK = 0,
@@ -91,9 +101,9 @@ int datum_ocean_set_stream(datum_ocean_t ctx, void *hip_stream, int use_own);
  * a patch is 384 bytes = three 128-byte lines: 16 x float4 (dx, dy, dz, nx), then 16 x float2 (ny, nz), texel
  * j = (y % PH) * PW + x % PW of the patch at 16 j and 256 + 8 j.
  *   byte offset of texel (x, y)'s patch = (x / B) * 24 N B + ((y / PH) * (B / PW) + (x % B) / PW) * 384
- * with (PW, PH, B, texel_bytes) from datum_ocean_map_layout (texel_bytes = 24; a build with -DOCEAN_MAP_COMPACT=0 keeps round
- * 3's 32-byte layout: groups of GX x GY texels, one 128-byte line each, 16 floats of layer 0 then 16 floats of layer 1).
- * datum_ocean_read_maps returns the reference's logical image [layer][y][x][4] with .w = 0. */
+ * with (PW, PH, B, texel_bytes) from datum_ocean_map_layout (texel_bytes = 24).
+ * datum_ocean_read_maps returns the reference's logical image [layer][y][x][4] with .w = 0 on the host,
+ * datum_ocean_export_maps writes the same image into device memory (a Vulkan-visible RGBA32F image). */
 int datum_ocean_bind_maps(datum_ocean_t ctx, void *device_ptr, size_t bytes);
 int datum_ocean_map_layout(int resolution, int *group_cols, int *group_rows, int *band, int *texel_bytes);
 int datum_ocean_maps_device(datum_ocean_t ctx, void **device_ptr, size_t *bytes);
@@ -202,6 +212,12 @@ int datum_ocean_farm_wait(datum_ocean_t ctx, int slot, float *collective_ms);
 
 /* blocking read-backs (host pointers).  maps: 2*N*N*4 floats. */
 int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps);
+
+/* The same image on the DEVICE: a cascade's displacement map as the reference's shaders see it (ocean.cpp:706, map.comp:79-80:
+ * N x N x 2 layers RGBA32F, [layer][y][x][4], .w = 0) written into caller-owned device memory of 2 * N * N * 16 bytes -- e.g. the
+ * imported memory of a linear VkImage / VkBuffer the renderer samples itself (datum_ocean_import_memory_fd).  One kernel on
+ * the handle's stream behind the last displace; the module's own 24-byte layout is untouched. */
+int datum_ocean_export_maps(datum_ocean_t ctx, int cascade, void *device_dst, size_t bytes);
 
 /* wait_fence (ocean.cpp:725) */
 int datum_ocean_sync(datum_ocean_t ctx);

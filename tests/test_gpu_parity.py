@@ -680,6 +680,34 @@ def test_bound_maps_and_caller_stream(capi, oracle, torch, N):
         oc.set_stream(None)
 
 
+@pytest.mark.parametrize("N,C", [(64, 1), (512, 3), (2048, 1), (4096, 1)])       # every patch shape, bands, a later cascade
+def test_export_maps_is_the_reference_image_on_the_device(capi, oracle, torch, N, C):
+    # datum_ocean_export_maps: a cascade's maps as the reference's N x N x 2 RGBA32F image (ocean.cpp:706, map.comp:79-80) in DEVICE
+    # memory -- what an integrator hands to a Vulkan sampler -- bit for bit what datum_ocean_read_maps gives the host
+    p = oracle.EXAMPLE
+    guard = 64
+    dst = torch.full((2 * N * N * 4 + guard,), 7.0, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    with capi.Ocean(N, C) as oc:
+        for c in range(C):
+            oc.set_cascade(c, p["wavescale"] * (c + 1), p["choppiness"])
+            oc.upload_state(c, make_state(oracle, N, 300 + c))
+        oc.update(DT)
+        oc.displace()
+        c = C - 1
+        oc.export_maps(c, dst.data_ptr(), 2 * N * N * 16)
+        oc.sync()
+        want = oc.read_maps(c)
+        with pytest.raises(capi.OceanError):
+            oc.export_maps(c, dst.data_ptr(), 2 * N * N * 16 - 1)          # too small a destination is refused
+        with pytest.raises(capi.OceanError):
+            oc.export_maps(C, dst.data_ptr(), 2 * N * N * 16)
+    got = dst.cpu().numpy()
+    assert np.array_equal(got[:2 * N * N * 4].reshape(2, N, N, 4), want)
+    assert np.all(got[2 * N * N * 4:] == 7.0)                                  # nothing written behind the image
+    assert np.all(want[..., 3] == 0) and float(np.abs(want[0, ..., 2]).max()) > 0
+
+
 @pytest.mark.parametrize("N", [256, 1024])
 def test_fp16_spectrum_against_oracle(capi, oracle, report, N):
     # BASELINE.json configs[4]: work spectrum stored as IEEE halves (8 B/pt between the passes), arithmetic fp32.
@@ -747,40 +775,6 @@ def test_fp16_spectrum_4096(capi, oracle, report):
     assert 1e-7 * scale < e16 < 2e-3 * scale
     assert n16 < 2e-2
     assert np.all(got[..., 3] == 0)
-
-
-def test_gen_split_launch_is_the_same_mesh(capi, oracle, torch, monkeypatch):
-    # datum_ocean_gen can launch a large mesh as two halves at the same time, the second on a stream of the module's, forked from
-    # and joined to the handle's stream by events (DATUM_OCEAN_GEN_SPLIT_ROWS at handle creation; off in the shipped build because
-    # the fork + join costs more than the overlap gains: profiles/r04_gen_levers.txt).  The mesh must be bit for bit the one
-    # launch's, with XCD chunks (1024^2 maps) and without (64^2), and work enqueued behind it must see all of it.
-    for N in (64, 1024):
-        p = oracle.EXAMPLE
-        h0 = make_state(oracle, N, 1000)
-        s = oracle.example_oceanset(N, swellphase=0.4)
-        hs = capi.OceanSet.from_buffer_copy(bytes(s))
-        out = []
-        for split in ("0", "512"):
-            monkeypatch.setenv("DATUM_OCEAN_GEN_SPLIT_ROWS", split)
-            verts = torch.zeros(1024 * 1024 * 12, dtype=torch.float32, device="cuda:0")
-            copy = torch.empty_like(verts)
-            stream = torch.cuda.Stream()
-            torch.cuda.synchronize()
-            with capi.Ocean(N, 1) as oc:
-                oc.set_stream(stream.cuda_stream)
-                oc.set_cascade(0, p["wavescale"], p["choppiness"])
-                oc.upload_state(0, h0)
-                oc.update(DT)
-                oc.displace()
-                oc.gen(0, hs, 1024, 1024, verts.data_ptr())
-                with torch.cuda.stream(stream):
-                    copy.copy_(verts)                     # enqueued behind gen on the handle's stream: must see both halves
-                stream.synchronize()
-                oc.set_stream(None)
-            out.append(copy.cpu())
-        monkeypatch.delenv("DATUM_OCEAN_GEN_SPLIT_ROWS")
-        assert bool(torch.isfinite(out[0]).all()) and float(out[0].abs().max()) > 0
-        assert torch.equal(out[0], out[1]), N
 
 
 def test_handles_come_and_go(capi, oracle, torch):

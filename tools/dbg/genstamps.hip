@@ -21,7 +21,9 @@ int main() {
   CK(hipMalloc(&maps, 2 * P * 16)); CK(hipMalloc(&verts, (size_t)sx * sy * 48));
   int const tiles = ((sx + GEN_TILE_X - 1) / GEN_TILE_X) * ((sy + GEN_TILE_Y - 1) / GEN_TILE_Y);
   CK(hipMalloc(&stamps, (size_t)tiles * 16 * 8)); CK(hipMemset(stamps, 0, (size_t)tiles * 16 * 8));
-  { std::vector<float4> h(2 * P); for (int y = 0; y < N; ++y) for (int x = 0; x < N; ++x) { h[map_index(N, y, x, 0)] = make_float4(0.1f * sinf(0.3f * x), 0.1f * cosf(0.2f * y), 0.2f * sinf(0.1f * (x + y)), 0); h[map_index(N, y, x, 1)] = make_float4(0.05f, 0.02f, 0.998f, 0); }
+  { std::vector<float4> h(2 * P); char *hb = reinterpret_cast<char*>(h.data());
+    for (int y = 0; y < N; ++y) for (int x = 0; x < N; ++x) { float a[4] = { 0.1f * sinf(0.3f * x), 0.1f * cosf(0.2f * y), 0.2f * sinf(0.1f * (x + y)), 0.05f }, b[2] = { 0.02f, 0.998f };
+      memcpy(hb + map_compact_a(N, y, x), a, 16); memcpy(hb + map_compact_b(N, y, x), b, 8); }
     CK(hipMemcpy(maps, h.data(), h.size() * 16, hipMemcpyHostToDevice)); }
   // the example camera's OceanSet (examples/ocean/ocean.cpp:33,63): position (0,0,8) looking along +x, fov 60 deg, 16:9; identity-free closed form
   datum_ocean_set set = {};

@@ -23,7 +23,7 @@ int main() {
 #ifndef STAMP_H16
 #define STAMP_H16 false
 #endif
-  constexpr int N = STAMP_N, C = STAMP_C; constexpr bool H = STAMP_H16; typedef RowCfg<N, H> RC; constexpr bool RW = RC::WALK, CW = (N >= OCEAN_COL_WALK_FROM); size_t P = (size_t)N*N;
+  constexpr int N = STAMP_N, C = STAMP_C; constexpr bool H = STAMP_H16; typedef RowCfg<N, H> RC; constexpr bool RW = RC::WALK, CW = col_walks<N, H>(); size_t P = (size_t)N*N;
   StepArgs a{};
   float2 *h0; float *phase; cd *spec; cf *tw; float4 *maps; float *omega; unsigned long long *stamps;
   CK(hipMalloc(&h0, C*P*8)); CK(hipMalloc(&phase, C*P*4)); CK(hipMalloc(&spec, C*P*16)); CK(hipMalloc(&maps, C*2*P*16));
