@@ -378,7 +378,8 @@ def main():
     # maps land in a torch tensor so that RCCL can gather them in place; kernels run on torch's stream
     maps = torch.empty(C * capi.map_block_floats(N), dtype=torch.float32, device=dev)
     oc.bind_maps(maps.data_ptr(), maps.numel() * 4)
-    stream = torch.cuda.Stream(dev)   # a real (non-default) stream: events and RCCL below are ordered on it too
+    # a real (non-default) stream: events and RCCL below are ordered on it too (DATUM_COMPUTE_PRIORITY: tools/gather_overhead.sh, -1 = high)
+    stream = torch.cuda.Stream(dev, priority=int(os.environ["DATUM_COMPUTE_PRIORITY"])) if "DATUM_COMPUTE_PRIORITY" in os.environ else torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     oc.set_stream(stream.cuda_stream)
     # the all-gather of north_star.  N > 1 (or --force-collective): the module's own farm (datum_ocean_farm_*: RCCL communicator,
@@ -464,8 +465,12 @@ def main():
     elif gathering and args.gather == "pipelined":
         slot = gather()
         gathers = 1
-        for _ in range(args.steps):
+        # (tools/gather_overhead.sh, stand-in only: DATUM_STANDIN_CHUNKS slices of the transfer, one every steps / chunks steps)
+        chunks = tg.standin_chunks if (tg is not None and getattr(tg, "standin_lib", None) is not None) else 1
+        for i in range(args.steps):
             step()
+            if chunks > 1 and (i + 1) % max(1, args.steps // chunks) == 0:
+                tg.launch_more()
     elif gathering:
         for _ in range(args.steps):
             step()

@@ -27,10 +27,18 @@ namespace
   // mode 4 / 5 / 6: as 0 / 2 / 3 with NON-TEMPORAL loads and stores (the `nt` bit: streaming data that should not displace what
   // the caches hold) -- if the step's slowdown under the stand-in is Infinity-Cache eviction it shrinks with these, if it is
   // plain bandwidth contention it does not (tools/gather_overhead.sh)
+  // mode 7 / 8 (round 5): as 0 / 3 with the destination WRAPPED into one peer's share of the gathered buffer -- the same bytes read and
+  // written, a seventh of the footprint: what of the slowdown is the 352 MB gathered buffer pushing the step's working set out of the
+  // 256 MiB Infinity Cache, and what is the bytes themselves
   typedef unsigned int u4_ __attribute__((ext_vector_type(4)));
 
   __global__ void __launch_bounds__(THREADS) standin_kernel(uint4 *dst, uint4 const *src, size_t bytes, int peers, float ticks_per_chunk, int mode)
   {
+    bool const wrap = mode >= 7;
+
+    if (wrap)
+      mode = (mode == 7) ? 0 : 3;
+
     bool const nt = mode >= 4;
 
     if (nt)
@@ -43,7 +51,7 @@ namespace
 
     for(size_t item = blockIdx.x; item < total; item += gridDim.x)
     {
-      size_t const peer = item / chunks, chunk = item % chunks;
+      size_t const peer = wrap ? 0 : item / chunks, chunk = item % chunks;
       size_t const first = chunk * (CHUNK / 16), last = min((chunk + 1) * (CHUNK / 16), bytes / 16);
 
       if (last - first == CHUNK / 16 && mode != 1)

@@ -17,6 +17,8 @@ This module holds the index arithmetic and the stream / buffer choreography so t
 gloo (tests/test_farm_gloo.py).  No compute happens here.
 """
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -129,6 +131,10 @@ class TileGather:
             self.standin_lib.datum_farm_standin_gather_mode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                                                         ctypes.c_double, ctypes.c_int, ctypes.c_void_p]
             self.standin_mode = int(os.environ.get("DATUM_STANDIN_MODE", "0"))    # tools/gather_overhead.sh: 1 resident only, 2 reads only, 3 writes only
+            # tools/gather_overhead.sh: the stand-in as this many launches over equal slices of the payload; launch() issues the first,
+            # launch_more() the next one (bench.py spreads them over the batch's steps)
+            self.standin_chunks = max(1, int(os.environ.get("DATUM_STANDIN_CHUNKS", "1")))
+            self.chunk_state = None
         self.world = world
         self.collective = world > 1 or force_collective
         self.device = torch.device(device)
@@ -144,7 +150,8 @@ class TileGather:
         self.acquired = None
         self.pending = []                    # launched, not yet handed out by result()
         if self.cuda:
-            self.comm = torch.cuda.Stream(self.device)
+            # (DATUM_COMM_PRIORITY: tools/gather_overhead.sh -- the communication stream below the compute stream)
+            self.comm = torch.cuda.Stream(self.device, priority=int(os.environ.get("DATUM_COMM_PRIORITY", "0"))) if "DATUM_COMM_PRIORITY" in os.environ else torch.cuda.Stream(self.device)
             self.packed = [torch.cuda.Event() for _ in range(slots)]
             self.timing = [None] * slots     # (start, stop) events around the slot's last collective
 
@@ -184,11 +191,8 @@ class TileGather:
                     if self.collective:
                         dist.all_gather_into_tensor(self.gathered[s], self.payload[s])
                     elif self.standin_lib is not None:
-                        n = self.payload[s].numel()
-                        rc = self.standin_lib.datum_farm_standin_gather_mode(self.gathered[s][n:].data_ptr(), self.payload[s].data_ptr(),
-                                                                             n * self.payload[s].element_size(), self.standin, self.standin_workgroups,
-                                                                             self.standin_gbps, self.standin_mode, self.comm.cuda_stream)
-                        assert rc == 0, f"datum_farm_standin_gather: {rc}"
+                        self.chunk_state = [s, 0]
+                        self._standin_chunk()
                     else:
                         n = self.payload[s].numel()
                         for k in range(1, 1 + self.standin):
@@ -200,6 +204,30 @@ class TileGather:
                 self.work[s] = dist.all_gather_into_tensor(self.gathered[s], self.payload[s], async_op=True)
         self.pending.append(s)
         return s
+
+    def _standin_chunk(self):
+        s, k = self.chunk_state
+        n = self.payload[s].numel()
+        es = self.payload[s].element_size()
+        per = (n * es // self.standin_chunks) & ~15
+        lo = k * per
+        nbytes = per if k + 1 < self.standin_chunks else n * es - lo
+        rc = self.standin_lib.datum_farm_standin_gather_mode(self.gathered[s][n:].data_ptr() + lo, self.payload[s].data_ptr() + lo, nbytes, self.standin,
+                                                             self.standin_workgroups, self.standin_gbps, self.standin_mode, self.comm.cuda_stream)
+        assert rc == 0, f"datum_farm_standin_gather: {rc}"
+        self.chunk_state[1] = k + 1
+
+    def launch_more(self):
+        """stand-in only: the next slice of the last launch()'s transfer, on the communication stream (no-op when all are out)"""
+        if self.standin_lib is None or self.chunk_state is None or self.chunk_state[1] >= self.standin_chunks:
+            return
+        s = self.chunk_state[0]
+        with torch.cuda.stream(self.comm):
+            self._standin_chunk()
+            stop = torch.cuda.Event(enable_timing=True)
+            stop.record(self.comm)
+            self.done[s] = stop
+            self.timing[s] = (self.timing[s][0], stop)
 
     def result(self):
         """Gathered buffer of the OLDEST launched batch (ordered by global grid index); the current stream waits for it."""
