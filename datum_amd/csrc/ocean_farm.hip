@@ -22,7 +22,15 @@
 
 #include <dlfcn.h>
 
-#include <rccl/rccl.h>
+// The handful of RCCL declarations the module uses, spelled out (values and layouts as in rccl/rccl.h of ROCm 6 / 7, which are
+// NCCL's): the module is built without RCCL's headers, so a renderer that never farms needs RCCL neither to run nor to BUILD.
+extern "C"
+{
+  typedef struct ncclComm *ncclComm_t;
+  typedef struct { char internal[128]; } ncclUniqueId;
+  typedef enum { ncclSuccess = 0 } ncclResult_t;            // (the other values only ever travel as integers and through ncclGetErrorString)
+  typedef enum { ncclInt8 = 0 } ncclDataType_t;             // the payload is gathered as bytes
+}
 
 namespace ocean
 {
@@ -34,9 +42,10 @@ namespace ocean
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;             // optional
     ncclResult_t (*AllGather)(void const*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     char const *(*GetErrorString)(ncclResult_t) = nullptr;
-    char const *(*GetLastError)(ncclComm_t) = nullptr;
+    char const *(*GetLastError)(ncclComm_t) = nullptr;           // optional: only adds RCCL's own text to an error
     ncclResult_t (*GetVersion)(int*) = nullptr;
   };
 
@@ -76,15 +85,31 @@ namespace ocean
 
       if (api.lib)
       {
-        #define OCEAN_RCCL_SYM(field, symbol) do { *reinterpret_cast<void**>(&api.field) = dlsym(api.lib, symbol); if (!api.field) { failure = std::string("RCCL library lacks ") + symbol; api.lib = nullptr; } } while(0)
-        OCEAN_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
-        OCEAN_RCCL_SYM(CommInitRank, "ncclCommInitRank");
-        OCEAN_RCCL_SYM(CommDestroy, "ncclCommDestroy");
-        OCEAN_RCCL_SYM(AllGather, "ncclAllGather");
-        OCEAN_RCCL_SYM(GetErrorString, "ncclGetErrorString");
-        OCEAN_RCCL_SYM(GetLastError, "ncclGetLastError");
-        OCEAN_RCCL_SYM(GetVersion, "ncclGetVersion");
-        #undef OCEAN_RCCL_SYM
+        // required symbols: the first one missing ends the resolution (api.lib is what every later lookup would go through)
+        struct { void **slot; char const *symbol; bool required; } const wanted[] = {
+          { reinterpret_cast<void**>(&api.GetUniqueId), "ncclGetUniqueId", true },
+          { reinterpret_cast<void**>(&api.CommInitRank), "ncclCommInitRank", true },
+          { reinterpret_cast<void**>(&api.CommDestroy), "ncclCommDestroy", true },
+          { reinterpret_cast<void**>(&api.AllGather), "ncclAllGather", true },
+          { reinterpret_cast<void**>(&api.GetErrorString), "ncclGetErrorString", true },
+          { reinterpret_cast<void**>(&api.GetVersion), "ncclGetVersion", true },
+          { reinterpret_cast<void**>(&api.GetLastError), "ncclGetLastError", false },
+          { reinterpret_cast<void**>(&api.CommAbort), "ncclCommAbort", false },
+        };
+
+        void *const lib = api.lib;
+
+        for(auto const &w : wanted)
+        {
+          *w.slot = dlsym(lib, w.symbol);
+
+          if (!*w.slot && w.required)
+          {
+            failure = std::string("RCCL library ") + api.path + " lacks " + w.symbol;
+            api.lib = nullptr;
+            break;
+          }
+        }
       }
     }
   };

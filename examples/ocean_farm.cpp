@@ -17,6 +17,7 @@
 #include <vector>
 
 #include <sys/wait.h>
+#include <signal.h>
 #include <unistd.h>
 
 namespace
@@ -219,12 +220,41 @@ int main(int argc, char **argv)
 
   int failed = relayed ? 0 : 1;
 
-  for(int r = 0; r < world; ++r)
+  // datum_ocean_farm_init is a collective with no timeout (ncclCommInitRank): a rank that died before it -- no device, no RCCL, a
+  // failed upload -- leaves the others waiting for ever.  So the ranks are reaped in the order they END, and the first one that
+  // ends badly (or an id that never made it round) takes the rest down instead of leaving the parent in waitpid.
+  int left = world;
+  bool culled = false;
+
+  while (left > 0)
   {
+    if (failed && !culled)
+    {
+      for(int r = 0; r < world; ++r)
+        if (pids[r] > 0)
+          kill(pids[r], SIGTERM);
+
+      culled = true;
+    }
+
     int status = 0;
-    waitpid(pids[r], &status, 0);
-    if (!WIFEXITED(status) || WEXITSTATUS(status) != 0)
-      failed += 1;
+    pid_t const who = waitpid(-1, &status, 0);
+
+    if (who < 0)
+      break;
+
+    for(int r = 0; r < world; ++r)
+    {
+      if (pids[r] == who)
+      {
+        pids[r] = -1;
+        left -= 1;
+
+        // (a rank ended by the cull above is a casualty, not a second failure -- but the run has failed either way)
+        if (!WIFEXITED(status) || WEXITSTATUS(status) != 0)
+          failed += 1;
+      }
+    }
   }
 
   printf("ocean_farm: %d ranks, %d x %d tiles, %d batches of %d steps: %s\n", world, N, N, batches, steps, failed ? "FAILED" : "ok");

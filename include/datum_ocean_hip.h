@@ -198,7 +198,10 @@ int datum_ocean_pack_displacement(datum_ocean_t ctx, int format, void *payload_d
  *   wait        blocks the host until it has; *collective_ms (may be NULL) = its duration on the communication stream
  *   shutdown    destroys communicator, stream and buffers (datum_ocean_destroy does it too)
  * RCCL is opened with dlopen at the first farm call (DATUM_OCEAN_RCCL_LIB, librccl.so.1): DATUM_OCEAN_EUNSUPPORTED when no
- * library is found; an ncclResult_t is reported as DATUM_OCEAN_ECOMM with RCCL's text in datum_ocean_last_error. */
+ * library is found; an ncclResult_t is reported as DATUM_OCEAN_ECOMM with RCCL's text in datum_ocean_last_error.
+ * datum_ocean_farm_init is a COLLECTIVE over the ranks (ncclCommInitRank) and RCCL gives it no timeout: it returns when every rank of
+ * the farm has called it, and not at all when one never does.  A launcher must therefore end the remaining ranks when one rank dies
+ * before its farm_init (examples/ocean_farm.cpp reaps its ranks in the order they end and does so; bench.py's launcher likewise). */
 #define DATUM_OCEAN_FARM_ID_BYTES 128
 int datum_ocean_farm_unique_id(void *id, size_t bytes);
 int datum_ocean_farm_init(datum_ocean_t ctx, void const *id, size_t bytes, int rank, int world, int format, int slots);

@@ -51,3 +51,17 @@ def test_a_failing_rank_fails_the_launcher():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plumbing"], env=_env(DATUM_BENCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "ranks failed" in r.stderr
+
+
+def test_farm_example_ends_when_its_ranks_fail():
+    # examples/ocean_farm.cpp without a GPU: rank 0 cannot make the communicator id, the others never get one; the parent reaps its ranks in
+    # the order they end, ends the rest and reports -- no hang in waitpid (datum_ocean_farm_init itself has no timeout: ADVICE r04)
+    exe = os.path.join(ROOT, "examples", "ocean_farm")
+    if not os.path.exists(exe):
+        pytest.skip("examples/ocean_farm is not built")
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("the GPU suite runs the example for real")
+    r = subprocess.run([exe, "3", "256", "1", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "FAILED" in r.stdout
