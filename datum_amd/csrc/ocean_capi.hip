@@ -182,11 +182,10 @@ namespace
     void *args[] = { &a };
     void const *kernel = wild ? reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16, true>) : reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>);
 
-    // work items = groups of row pairs x cascades: one workgroup each, or (largest grids) one persistent workgroup per
-    // compute unit that walks its share
+    // work items = groups of row pairs x cascades: one workgroup each
     int const items = C::GROUPS * ctx->cascades;
 
-    return launch(kernel, dim3(C::WALK ? std::min(items, ctx->cus * C::PER_CU) : items), dim3(C::THREADS), args, C::LDS, ctx->stream, ev);
+    return launch(kernel, dim3(items), dim3(C::THREADS), args, C::LDS, ctx->stream, ev);
   }
 
   template<int N>

@@ -680,28 +680,26 @@ namespace ocean
     static constexpr int PAIR_THREADS = 128;
     static constexpr int PAIRS = (2 * T >= PAIR_THREADS) ? 1 : PAIR_THREADS / (2 * T);   // row pairs per workgroup
     static constexpr int THREADS = 2 * T * PAIRS;
-    // SEQ: the two packed fields one after the other through ONE LDS line per row (half the LDS), the other waits in registers -- at
-    // 2048^2, and at 4096^2 with the fp16-stored spectrum only: as halves C's results wait in 16 registers, as floats in 32 and the
-    // kernel spills (4096^2 fp32: 155 against 132 us walking)
-    static constexpr bool SEQ = (N >= 2048) && (H16 || N == 2048);
+    // SEQ (from 1024^2 up): the two packed fields one after the other through ONE LDS line per row (half the LDS: two 512-thread
+    // row pairs per CU at 4096^2, three or four 256-thread ones at 2048^2, SIX at 1024^2), the other field waits in registers.
+    // Up to round 4 the fp32 spectrum at 4096^2 spilled in this form (C's results wait in 32 registers: 155 us) and ran as one
+    // persistent 1024-thread workgroup per CU that walked its pairs with the next pair's inputs requested early (131-132 us); with
+    // round 5's registers (122, no spill) the sequential form is the faster one there too: 120.4-121.8 against 123.0-123.6 us, and the
+    // walking form is gone.  At 1024^2 the form lost in round 4 (28.9 against 25.2 us, 100 registers compiled for four per CU); with
+    // round 5's layouts it needs 80 registers and 18.9 KB, six workgroups per CU instead of four: 24.1 against 25.2 us
+    // (profiles/r05_rowpass_forms.txt).  Not below: 512^2 is latency-bound and the form doubles the barrier phases.
+    static constexpr bool SEQ = N >= 1024;
     static constexpr int K = SEQ ? 1 : 2;                                  // LDS lines per row
-    // the prologue two slots per instruction -- not in the sequential form, whose registers are full (4096^2 fp16: 56 bytes of
-    // spill and 134 us packed against 28 bytes and 124-128 us: profiles/r04_rowpass_packed.txt)
-    static constexpr bool PACKED = !SEQ;
+    // the prologue two slots per instruction -- not from 2048^2 up, where the sequential form's registers are full (4096^2 fp16: 56
+    // bytes of spill and 134 us packed against 28 bytes and 124-128 us: profiles/r04_rowpass_packed.txt)
+    static constexpr bool PACKED = N <= 1024;
     static constexpr int LINE = LineFFT<N, 1, E>::LINE;                    // >= N + 2: element 0 once more at index N (the Hermitian swap)
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
-    static constexpr bool WALK = (N >= 4096) && PAIRS == 1 && !SEQ;       // see ocean_rowpass_kernel
-    static constexpr int STASH = 1 + LineTwiddles<N, E>::NMIDREG + Plan<N, E>::M;             // per-thread twiddles the walking variant keeps in LDS between pairs
-    static constexpr size_t LDS = ((size_t)LineFFT<N, 1, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE + (WALK ? (size_t)STASH * T : 0)) * sizeof(cf);
+    static constexpr size_t LDS = ((size_t)LineFFT<N, 1, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE) * sizeof(cf);
 
     static constexpr int FIT = (int)(((size_t)160 * 1024) / LDS);                              // workgroups per CU the LDS allows
-    static constexpr int PER_CU = (FIT < 2) ? (FIT < 1 ? 1 : FIT) : 2;                         // persistent workgroups per compute unit (walking)
-    static constexpr int SEQ_PER_CU = (N == 2048) ? 3 : 4;                                     // sequential form: workgroups per CU the registers are budgeted for
-    static constexpr int MIN_WAVES = WALK ? (THREADS / 64) * PER_CU / 4 : (SEQ ? ((THREADS / 64) * (FIT > SEQ_PER_CU ? SEQ_PER_CU : FIT) + 3) / 4 : 1);   // per SIMD, for __launch_bounds__
-
-    // walking form: the parts of the next pair's inputs requested BEFORE the transforms (see request): h0 and its mirror row;
-    // the rest between the last exchange and the last pass
-    static constexpr int EARLY = 3;
+    static constexpr int SEQ_PER_CU = (N == 2048) ? 3 : (N == 1024 ? 6 : 4);                                     // sequential form: workgroups per CU the registers are budgeted for
+    static constexpr int MIN_WAVES = SEQ ? ((THREADS / 64) * (FIT > SEQ_PER_CU ? SEQ_PER_CU : FIT) + 3) / 4 : 1;   // per SIMD, for __launch_bounds__
 
     static_assert((N / 2) % PAIRS == 0, "row pairs per workgroup must divide N / 2");
   };
@@ -747,21 +745,7 @@ namespace ocean
     }
   }
 
-  // One group of row pairs per workgroup -- except at 4096^2 with the fp32 spectrum (RowCfg::WALK), where one 1024-thread workgroup fills a CU
-  // (LDS) and a pair's phases ran one after the other with 4-5 us between two workgroups on a CU (store drain + launch):
-  // there the workgroups are persistent and walk their pairs.  The next pair's inputs are requested BEFORE the current
-  // pair's stores, so that the wait for them counts past those stores and the stores drain under the next pair's
-  // arithmetic -- and as early as the 128 registers a thread may have there allow: h0 and its mirror row (32 registers,
-  // RowCfg::EARLY) before the transforms, phase and dispersion (16) between the last exchange and the last pass, where
-  // the value registers are free (fft_lines' before_last hook).  4096^2: 178 us one pair per workgroup, 161-168 us walking
-  // with everything requested behind the transforms, 135-137 us so; all 48 before the transforms spill (191 us), h0 +
-  // mirror + phase fits and is slower (146-150 us): profiles/r02_4096_second_pass.txt.  What it took to keep hipcc from
-  // spilling (a spill's reload is a vector-memory load whose wait drains the very stores that should overlap): the request
-  // is unconditional (the last pair requests itself again: under "if (more)" the old inputs stay live as the other arm of
-  // the merge), the thread's twiddles wait in LDS between pairs, and its coordinates are re-derived per pair from an opaque
-  // copy of its index.  (Two rows per thread in 512-thread workgroups: 96 registers of inputs on top of 209 in 256.)
-  template<int N, bool H16 = false> constexpr bool row_walks() { return RowCfg<N, H16>::WALK; }
-
+  // One group of row pairs per workgroup.
   // WILD: a phase may lie outside [0, 2 pi) (sincos_phase_pair); its own instantiation rather than a branch in the kernel: the
   // registers of the second path cost the 4096^2 fp16 form 12 more bytes of spill and 6 us (profiles/r04_rowpass_packed.txt)
   template<int N, bool H16, bool WILD = false>
@@ -792,7 +776,7 @@ namespace ocean
     auto group_of = [&](int item) { int const q = item % G; return (G % 8 == 0) ? (q & 7) * (G / 8) + (q >> 3) : q; };
 
     int const pr = threadIdx.x / (2 * T);
-    int half = (threadIdx.x % (2 * T)) / T;           // (the walking variant re-derives it per item)
+    int const half = (threadIdx.x % (2 * T)) / T;
     int const t_ = threadIdx.x % T;
 
     size_t const plane = (size_t)N * N;
@@ -816,8 +800,7 @@ namespace ocean
       float2 hk[E], hm[E];
     };
 
-    // parts: 1 = h0, 2 = h0's mirror row, 4 = phase, 8 = dispersion
-    auto request = [&](int item, int t, Inputs &in, int parts = 15)
+    auto request = [&](int item, int t, Inputs &in)
     {
       int const cascade = item / G;
       int const y = row_of(item);
@@ -834,15 +817,12 @@ namespace ocean
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
-        if (parts & 4)
-          in.ph[s] = buf_load_f32(rphase, e0 * 4, T * s * 4);
-        if (parts & 1)
-          in.hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
-        if (parts & 2)
-          in.hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
+        in.ph[s] = buf_load_f32(rphase, e0 * 4, T * s * 4);
+        in.hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
+        in.hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
       }
 
-      if (advance && (parts & 8))
+      if (advance)
       {
         // dispersion_lookup (ocean_omega_kernel's quadrant table) through the buffer path.  |x - N/2| of slot s is N/2 - t - T s in the
         // lower half of the slots and t + T (s - E/2) in the upper: two per-thread offsets and compile-time steps, not one address
@@ -868,55 +848,11 @@ namespace ocean
     OCEAN_STAMP_WHERE();
     OCEAN_STAMP(0);
 
-    constexpr bool WALK = row_walks<N, H16>();
-
-    cf *twstash = midtab + L::MIDTAB + C::PAIRS * 2 * K * C::LINE;       // [STASH][T], walking only
-
-    if constexpr (WALK)
+    auto one_item = [&](int item, Inputs &in)
     {
-      if (half == 0)
-      {
-        twstash[t_] = ca_;
-
-        #pragma unroll
-        for(int k = 0; k < LineTw<N, E>::type::NMIDREG; ++k)
-          twstash[(1 + k) * T + t_] = w_.mid[k];
-
-        #pragma unroll
-        for(int m = 0; m < P::M; ++m)
-          twstash[(1 + LineTw<N, E>::type::NMIDREG + m) * T + t_] = w_.last[m];
-      }
-
-      __syncthreads();
-    }
-
-    auto one_item = [&](int item, Inputs &in, int next)
-    {
-      int t = t_;
-      cf ca = ca_;
-      typename LineTw<N, E>::type w = w_;
-
-      if constexpr (WALK)
-      {
-        // (an opaque copy of the thread's index: everything derived from its coordinates belongs to the pair, or hipcc hoists it out
-        // of the loop into registers that the pair's arithmetic needs; the thread's twiddles wait in the LDS between pairs)
-        int tid = (int)threadIdx.x;
-
-        asm volatile("" : "+v"(tid));
-
-        t = tid % T;
-        half = (tid % (2 * T)) / T;
-
-        ca = twstash[t];
-
-        #pragma unroll
-        for(int k = 0; k < LineTw<N, E>::type::NMIDREG; ++k)
-          w.mid[k] = twstash[(1 + k) * T + t];
-
-        #pragma unroll
-        for(int m = 0; m < P::M; ++m)
-          w.last[m] = twstash[(1 + LineTw<N, E>::type::NMIDREG + m) * T + t];
-      }
+      int const t = t_;
+      cf const ca = ca_;
+      typename LineTw<N, E>::type const &w = w_;
 
       OCEAN_STAMP(1);
 
@@ -1112,24 +1048,14 @@ namespace ocean
 
       OCEAN_STAMP(3);
 
-      if constexpr (WALK)
-        request(next, t, in, C::EARLY);
-
-      // the rest between the last exchange and the last pass, where the value registers are free
-      auto rest = [&]()
-      {
-        if constexpr (WALK)
-          request(next, t, in, 15 & ~C::EARLY);
-      };
-
       if constexpr (C::SEQ)
       {
         // C through the row's line, then D through the same line; C's results wait in registers for the one store per point
         fft_lines<N, 1, 1, E>(reinterpret_cast<cf (&)[1][E]>(v[0]), t, line, C::LINE, midtab, w, true);
-        fft_lines<N, 1, 1, E>(reinterpret_cast<cf (&)[1][E]>(v[1]), t, line, C::LINE, midtab, w, true, rest);
+        fft_lines<N, 1, 1, E>(reinterpret_cast<cf (&)[1][E]>(v[1]), t, line, C::LINE, midtab, w, true);
       }
       else
-        fft_lines<N, K, 1, E>(v, t, line, C::LINE, midtab, w, true, rest);
+        fft_lines<N, K, 1, E>(v, t, line, C::LINE, midtab, w, true);
 
       OCEAN_STAMP(4);
 
@@ -1160,19 +1086,7 @@ namespace ocean
 
     OCEAN_WAIT_LOADS();
 
-    if constexpr (!WALK)
-      one_item(item, in, item);
-    else
-    {
-      int const stride = (int)gridDim.x;
-      int const items = G * a.cascades;
-
-      // first item peeled: the counted wait at the top of the loop body needs one history on every path into it
-      one_item(item, in, item + stride < items ? item + stride : item);
-
-      for(item += stride; item < items; item += stride)
-        one_item(item, in, item + stride < items ? item + stride : item);
-    }
+    one_item(item, in);
   }
 
   template<int N>

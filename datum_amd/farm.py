@@ -124,7 +124,6 @@ class TileGather:
         self.standin_lib = None
         if standin_peers and standin_workgroups:
             import ctypes
-            import os
 
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdatum_farm_standin.so")
             self.standin_lib = ctypes.CDLL(path)      # fails loudly when the library was not built

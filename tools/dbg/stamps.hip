@@ -23,7 +23,7 @@ int main() {
 #ifndef STAMP_H16
 #define STAMP_H16 false
 #endif
-  constexpr int N = STAMP_N, C = STAMP_C; constexpr bool H = STAMP_H16; typedef RowCfg<N, H> RC; constexpr bool RW = RC::WALK, CW = col_walks<N, H>(); size_t P = (size_t)N*N;
+  constexpr int N = STAMP_N, C = STAMP_C; constexpr bool H = STAMP_H16; typedef RowCfg<N, H> RC; constexpr bool RW = false, CW = col_walks<N, H>(); size_t P = (size_t)N*N;
   StepArgs a{};
   float2 *h0; float *phase; cd *spec; cf *tw; float4 *maps; float *omega; unsigned long long *stamps;
   CK(hipMalloc(&h0, C*P*8)); CK(hipMalloc(&phase, C*P*4)); CK(hipMalloc(&spec, C*P*16)); CK(hipMalloc(&maps, C*2*P*16));
@@ -37,10 +37,10 @@ int main() {
   a.h0=h0; a.phase=phase; a.spec=spec; a.maps=maps; a.tw=tw; a.omega=omega; a.ndt=1; a.cascades=C; a.dt[0]=1.f/60; a.stamps=stamps;
   for (int c=0;c<DATUM_OCEAN_MAX_CASCADES;++c) a.casc[c] = CascadeConst{22.f, 1/22.f, 1.35f, 4/(N/22.f), 1.f, 1.f};
   CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC::LDS));
-  CK(hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS));
+  CK(hipFuncSetAttribute(colpass_entry<N, H>(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS));
   for (int it = 0; it < 5; ++it) {
     hipLaunchKernelGGL((ocean_rowpass_kernel<N, H>), dim3(RW ? 256 : RC::GROUPS * C), dim3(RC::THREADS), RC::LDS, 0, a);
-    hipLaunchKernelGGL((ocean_colpass_kernel<N, H>), dim3(CW ? 256 : ColCfg<N>::TILES * C), dim3(ColCfg<N>::THREADS), ColCfg<N>::LDS, 0, a);
+    { void *args[] = { &a }; CK(hipLaunchKernel(colpass_entry<N, H>(), dim3(CW ? 256 : ColCfg<N>::TILES * C), dim3(ColCfg<N>::THREADS), args, ColCfg<N>::LDS, 0)); }
   }
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> st(nst); CK(hipMemcpy(st.data(), stamps, nst*8, hipMemcpyDeviceToHost));
