@@ -314,6 +314,47 @@ namespace ocean
     }
   };
 
+  // 8-point transform of v[r] w^r with the twiddle w^r = w^a (w^2)^b of index r = a + 2b applied in two steps (see idft16_twiddled):
+  // four twiddle values live (w, w^2, w^4, w^6) instead of seven powers, the same 13 complex products (3 + 10 against 6 + 7)
+  OC_HD void idft8_twiddled(cf (&v)[8], cf w1)
+  {
+    const float h = 0.70710678118654752440f;
+
+    {
+      cf const w2 = cmul(w1, w1);
+      cf const w4 = cmul(w2, w2);
+      cf const w6 = cmul(w4, w2);
+
+      v[2] = cmul(v[2], w2);  v[3] = cmul(v[3], w2);
+      v[4] = cmul(v[4], w4);  v[5] = cmul(v[5], w4);
+      v[6] = cmul(v[6], w6);  v[7] = cmul(v[7], w6);
+    }
+
+    // index = a + 2b: 4-point transforms over b for a = 0, 1
+    idft4(v[0], v[2], v[4], v[6]);
+    idft4(v[1], v[3], v[5], v[7]);
+
+    // ... and by w^a
+    v[1] = cmul(v[1], w1);
+    v[3] = cmul(v[3], w1);
+    v[5] = cmul(v[5], w1);
+    v[7] = cmul(v[7], w1);
+
+    // t[1][c] *= exp(2 pi i c / 8):  t1 = h (1 + i) v3,  t3 = -h (1 - i) v7, the factor h folded into the sums
+    cf s1 = add_muli(v[3], v[3]);
+    cf s3 = sub_muli(v[7], v[7]);
+
+    cf o[8];
+    o[0] = v[0] + v[1];  o[4] = v[0] - v[1];
+    o[1] = fma_real(v[2], s1, h);   o[5] = fms_real(v[2], s1, h);
+    o[2] = add_muli(v[4], v[5]);    o[6] = sub_muli(v[4], v[5]);
+    o[3] = fms_real(v[6], s3, h);   o[7] = fma_real(v[6], s3, h);
+
+    OC_UNROLL
+    for(int i = 0; i < 8; ++i)
+      v[i] = o[i];
+  }
+
   // 16-point transform of v[r] w^r (the last pass of 4096 = 16^3): the twiddle w^r = w^a (w^4)^b of index r = a + 4b is applied in
   // two steps, (w^4)^b in front of the 4-point transforms over b and w^a behind them -- six twiddle values live (w, w^2, w^3 and
   // w^4, w^8, w^12) instead of the fifteen powers of a product tree (thirty registers beside the thirty-two of the values: the
@@ -429,6 +470,11 @@ namespace ocean
 
       Radix<R>::run(u);
     }
+  };
+
+  template<> struct TwiddledDft<8>
+  {
+    static OC_HD void run(cf (&u)[8], cf w1) { idft8_twiddled(u, w1); }
   };
 
   template<> struct TwiddledDft<16>
@@ -568,12 +614,9 @@ namespace ocean
       {
         constexpr int MI = (PASS >= 2 && PASS - 2 < NMIDREG) ? PASS - 2 : 0;
 
-        cf p[E];
-        twiddle_powers<E>(w.mid[MI], p);
+        twiddled_dft<E>(v, w.mid[MI]);
 
-        OC_UNROLL
-        for(int r = 1; r < E; ++r)
-          v[r] = cmul(v[r], p[r]);
+        return;
       }
 
       Radix<E>::run(v);

@@ -1093,10 +1093,13 @@ namespace ocean
   struct ColCfg
   {
     // 16 points per thread at 1024^2 (1024 = 16 x 16 x 4: three passes, two exchanges, 256-thread tiles of four columns),
-    // with the two fields one after the other (half the LDS: 37 KB, three workgroups per CU at 148 registers): column pass
-    // 34.2 -> 31.3 us, 65.8 k -> 69 k grids/s (tools/ab_4096.sh, profiles/r02_col_radix16.txt).  Not elsewhere: 512^2 8.2
-    // against 5.5 us, 2048^2 x 4 168 against 160 us, 4096^2 170-187 (erratic) against 174-175 us.
-    static constexpr int E = (N == 1024) ? 16 : default_radix(N);         // points per thread
+    // with the two fields one after the other (half the LDS: 35 KB, four workgroups per CU at 124 registers): column pass
+    // 34.2 -> 31.3 us in round 2 (profiles/r02_col_radix16.txt).  Round 5: the same at 2048^2 (2048 = 16 x 16 x 8: 512-thread tiles, 66 KB,
+    // TWO per CU, one tile per workgroup instead of one persistent 1024-thread workgroup per CU that walks its tiles): 31.5 -> 26.5 us
+    // at 2048^2 x 1, 144.7 -> 137-143 us at x 4 -- in round 4's layouts the form was a loss there (168 against 160 us).  Not at 4096^2,
+    // whose maps are beyond the Infinity Cache: 173 against 147 us (the walking form's prefetch overlaps HBM-bound stores), nor at
+    // 512^2 (8.2 against 5.5 us).  profiles/r05_colpass_forms.txt
+    static constexpr int E = (N == 1024 || N == 2048) ? 16 : default_radix(N);         // points per thread
     static constexpr int T = Plan<N, E>::T;
     static constexpr int K = (E == 16) ? 1 : 2;                            // fields per set of barrier phases: 2 = together, 1 = one after the other (half the LDS)
     // LDS: the W columns of a tile element by element in one array per field (position * W + column: threads are
@@ -1111,6 +1114,7 @@ namespace ocean
     static constexpr int WCAP = WRAW > 8 ? 8 : (WRAW < 1 ? 1 : WRAW);
     static constexpr int W = WCAP < WFIT ? WCAP : WFIT;                 // columns per workgroup, one per thread group
     static constexpr int THREADS = W * T;
+    static constexpr int MIN_WAVES = (N == 2048) ? 4 : 1;        // per SIMD, for __launch_bounds__: two 512-thread tiles per CU at 2048^2 (128 registers, 20 bytes of spill)
     static constexpr int CS = LineFFT<N, W, E>::LINE;                      // elements per column line
     static constexpr int TILES = N / W;
 
@@ -1124,15 +1128,15 @@ namespace ocean
     static_assert(OFF_MAIN % 16 == 0, "LDS carve must stay 16-byte aligned");
   };
 
-  // N <= 1024: one tile per workgroup (2-4 workgroups per CU overlap each other's memory and arithmetic phases; a
-  // persistent variant was measured 15 % slower there).  N >= 2048: one 1024-thread workgroup fills a CU (LDS) and its
+  // N <= 2048: one tile per workgroup (2-4 workgroups per CU overlap each other's memory and arithmetic phases; a
+  // persistent variant was measured 15 % slower at 1024^2).  N = 4096: one 1024-thread workgroup fills a CU (LDS) and its
   // phases -- 8 loads per thread, the transforms, 16 stores per thread -- ran one after the other (4096^2: 64 us of
   // transforms + 72 us of loads + 110 us of stores = the 247 us measured).  There the workgroups are persistent: each
   // walks a run of tiles, requests the next tile's values before transforming the current one and lets the current
   // tile's stores drain under the next tile's transforms.
   // measured (profiles/r02_large_grids.txt), with the band layouts: 2048^2 x 4 182 -> 168 us, 4096^2 219 -> 210 us; without
   // them 208 -> 187 us and 248 -> 259 us (not every step of this was a gain on its own)
-  template<int N, bool H16> constexpr bool col_walks() { return N >= 2048; }
+  template<int N, bool H16> constexpr bool col_walks() { return N >= 4096; }
 
   // PLAIN: the maps' stores are not written through (col_plain_maps: the sizes at which several cascades' maps are far
   // beyond the Infinity Cache although one cascade's are not; the policy is part of the instruction, hence a template flag)
@@ -1388,7 +1392,7 @@ namespace ocean
   }
 
   template<int N, bool H16, bool PLAIN = false>
-  __global__ void OCEAN_LDS_UNPAIRED __launch_bounds__(ColCfg<N>::THREADS) ocean_colpass_kernel(StepArgs a)
+  __global__ void OCEAN_LDS_UNPAIRED __launch_bounds__(ColCfg<N>::THREADS, ColCfg<N>::MIN_WAVES) ocean_colpass_kernel(StepArgs a)
   {
     colpass_body<N, H16, PLAIN>(a);
   }
@@ -1402,7 +1406,7 @@ namespace ocean
   namespace paired
   {
     template<int N, bool H16, bool PLAIN = false>
-    __global__ void __launch_bounds__(ColCfg<N>::THREADS) ocean_colpass_kernel(StepArgs a)
+    __global__ void __launch_bounds__(ColCfg<N>::THREADS, ColCfg<N>::MIN_WAVES) ocean_colpass_kernel(StepArgs a)
     {
       colpass_body<N, H16, PLAIN>(a);
     }
