@@ -84,15 +84,25 @@ def parse():
     return ap.parse_args()
 
 
+def _code_only(text):
+    """C++ source without its comments and with every run of white space collapsed: what the compiler sees, not how it is documented"""
+    import re
+
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", " ", text).strip()
+
+
 def kernel_source_hash():
-    """sha256 over the sources of the two step kernels and their launch code (ocean.gen lives in its own file and is not one of the
-    kernels the traffic file covers): a committed PMC measurement is only quoted for the build it was made on."""
+    """sha256 over the CODE (comments and white space stripped: _code_only) of the two step kernels and their launch code (ocean.gen lives
+    in its own file and is not one of the kernels the traffic file covers): a committed PMC measurement is only quoted for the build it
+    was made on, and a comment edited afterwards does not orphan it."""
     import hashlib
 
     h = hashlib.sha256()
     for name in ("ocean_kernels.hip", "ocean_fft_core.h", "ocean_capi.hip"):
-        with open(os.path.join(ROOT, "datum_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "datum_amd", "csrc", name), "r") as f:
+            h.update(_code_only(f.read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -5,20 +5,20 @@
 //
 //   row pass    update_ocean phase advance (ocean.cpp:223-233) + ocean.sim (data/ocean.sim.comp:44-79)
 //               + ocean.fftx (data/ocean.fftx.comp:49-100) of TWO packed fields (see "packed step" below),
-//               N/8 threads per row, rows y and N-y per workgroup
+//               N/8 (N/16 from 2048^2 up) threads per row, rows y and N-y per workgroup
 //               reads  h0 (8 B/pt, plus its mirror row through L2), phase (4)   writes phase (4), spectrum (16)
 //   column pass ocean.ffty (data/ocean.ffty.comp:49-100) + ocean.map (data/ocean.map.comp:51-82),
 //               one workgroup per tile of W columns, one column per thread group
 //               reads spectrum (16)    writes the two map layers without their zero .w channels (24: map_compact_a)
 //
 // = 72 bytes of HBM traffic per grid point; the algorithm as the reference states it (three transforms) has
-// 96 algorithmic bytes per point (the figure bench.py's roofline uses) and the reference as
+// 96 algorithmic bytes per point (bench.py's roofline.frac_on_survey_bytes) and the reference as
 // written moves 196.
 //
 // Work spectrum layout (private to these kernels): per cascade, 8 x 8 blocks of 16-byte values (C, D),
 // [y/8][x/8][y%8][x%8]: a row of a block is one 128-byte line; a column-pass wave reads whole blocks.  The largest grids
 // keep the columns one XCD works on at a time contiguous ([x/B][...]: blocked_at, band_cols), for the maps too (map_compact_patch).
-// From 2048^2 up the column pass's workgroups are persistent and walk their tiles, at 4096^2 the row pass's too.
+// At 4096^2 the column pass's workgroups are persistent and walk their tiles; everything else is one work item per workgroup.
 //
 // Built with -ffp-contract=off: products and sums are rounded as written (the phase state is
 // bit-identical to the host formula); the FFT butterflies ask for their FMAs explicitly.
