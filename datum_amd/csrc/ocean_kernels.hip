@@ -533,10 +533,29 @@ namespace ocean
   // `before_last` runs between the last exchange and the last pass: every value of the lines is in LDS then and the
   // threads' value registers are free (the walking column pass requests its next tile there)
   // W: lines interleaved element by element (`line` points at this thread's line, element positions W apart): LineFFT
+  // between the two sides of an exchange: a workgroup barrier, or -- where the line belongs to ONE wave -- a wave-level fence
+  template<bool WAVE>
+  __device__ __forceinline__ void exchange_sync()
+  {
+    if constexpr (WAVE)
+    {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    else
+      __syncthreads();
+  }
+
   template<int N, int K, int W, int E_, typename Hook = NoHook>
   __device__ __forceinline__ void fft_lines(cf (&v)[K][E_], int t, cf *line, int linestride, cf const *midtab, typename LineTw<N, E_>::type const &w, bool active, Hook before_last = Hook())
   {
     typedef LineFFT<N, W, E_> L;
+
+    // a line whose T threads are exactly one wave (row pass, W = 1, T = 64: 512^2) is exchanged without workgroup barriers: a wave's LDS
+    // operations execute in order, a fence that completes its stores is all an exchange needs (512^2 x 1 11.6-11.7 -> 11.5 us, x 4 row pass
+    // 11.4 -> 11.0 us; at 1024^2 with 16 points per thread -- one wave per row too -- it changes nothing: profiles/r05_rowpass_forms.txt)
+    constexpr bool WAVE = (W == 1) && (Plan<N, E_>::T == 64);
 
     if (active)
     {
@@ -545,7 +564,7 @@ namespace ocean
         L::pass0(v[k], t, line + k * linestride);
     }
 
-    __syncthreads();
+    exchange_sync<WAVE>();
 
     if (Plan<N, E_>::NP >= 3)
     {
@@ -556,7 +575,7 @@ namespace ocean
           L::template mid_load<1>(v[k], t, line + k * linestride, midtab, w);
       }
 
-      __syncthreads();
+      exchange_sync<WAVE>();
 
       if (active)
       {
@@ -565,7 +584,7 @@ namespace ocean
           L::template mid_store<1>(v[k], t, line + k * linestride);
       }
 
-      __syncthreads();
+      exchange_sync<WAVE>();
     }
 
     if (Plan<N, E_>::NP >= 4)
@@ -577,7 +596,7 @@ namespace ocean
           L::template mid_load<2>(v[k], t, line + k * linestride, midtab, w);
       }
 
-      __syncthreads();
+      exchange_sync<WAVE>();
 
       if (active)
       {
@@ -586,7 +605,7 @@ namespace ocean
           L::template mid_store<2>(v[k], t, line + k * linestride);
       }
 
-      __syncthreads();
+      exchange_sync<WAVE>();
     }
 
     if (Plan<N, E_>::NP >= 5)
@@ -598,7 +617,7 @@ namespace ocean
           L::template mid_load<3>(v[k], t, line + k * linestride, midtab, w);
       }
 
-      __syncthreads();
+      exchange_sync<WAVE>();
 
       if (active)
       {
@@ -607,7 +626,7 @@ namespace ocean
           L::template mid_store<3>(v[k], t, line + k * linestride);
       }
 
-      __syncthreads();
+      exchange_sync<WAVE>();
     }
 
     if (Plan<N, E_>::NP >= 6)
@@ -619,7 +638,7 @@ namespace ocean
           L::template mid_load<4>(v[k], t, line + k * linestride, midtab, w);
       }
 
-      __syncthreads();
+      exchange_sync<WAVE>();
 
       if (active)
       {
@@ -628,7 +647,7 @@ namespace ocean
           L::template mid_store<4>(v[k], t, line + k * linestride);
       }
 
-      __syncthreads();
+      exchange_sync<WAVE>();
     }
 
     before_last();
@@ -640,7 +659,7 @@ namespace ocean
         L::last(v[k], t, line + k * linestride, w);
     }
 
-    __syncthreads();
+    exchange_sync<WAVE>();
   }
 
   //|---------------------- packed step: two complex transforms instead of three --
