@@ -94,8 +94,16 @@ def line_sites(p, lay, NP_sites=True):
     return sites
 
 
+QUIET = False
+
+
 def report(title, rows):
     ti = ta = 0
+    if QUIET:
+        for name, kind, n, i, a in rows:
+            ti += i
+            ta += a
+        return ti, ta
     print(title)
     for name, kind, n, i, a in rows:
         ti += i
@@ -187,9 +195,10 @@ def colpass(N, E, ps, W, cs_extra, K, scheme="pad"):
 
 
 SHIPPED = {
-    # N: (row E, row K, col E, col W, col K)
-    64: (4, 2, 4, 8, 2), 128: (8, 2, 8, 8, 2), 256: (8, 2, 8, 8, 2), 512: (8, 2, 8, 4, 2), 1024: (8, 2, 16, 4, 1),
-    2048: (16, 1, 8, 4, 2), 4096: (16, 1, 8, 2, 2),
+    # N: (row E, row K, col E, col W, col K) -- RowCfg / ColCfg of datum_amd/csrc/ocean_kernels.hip at the end of round 5
+    # (K = LDS lines per row / fields per set of barrier phases; the ROUND-4 paddings below are modelled on the same shapes)
+    64: (4, 2, 4, 8, 2), 128: (8, 2, 8, 8, 2), 256: (8, 2, 8, 8, 2), 512: (8, 2, 8, 2, 2), 1024: (8, 1, 16, 4, 1),
+    2048: (16, 1, 16, 4, 1), 4096: (16, 1, 8, 2, 2),
 }
 
 if __name__ == "__main__" and "--new" not in __import__("sys").argv:
@@ -290,10 +299,13 @@ def x_kernel(title, N, E, W, rowswap):
 
 
 def new_scheme(sizes):
+    """{(kernel, N): (ideal, actual) LDS cycles} of the shipped layouts"""
+    out = {}
     for N in sizes:
         rE, rK, cE, cW, cK = SHIPPED[N]
-        x_kernel(f"[round 5 layout] row pass N={N} E={rE} T={N // rE}", N, rE, 1, True)
-        x_kernel(f"[round 5 layout] column pass N={N} E={cE} T={N // cE} W={cW}", N, cE, cW, False)
+        out[("row", N)] = x_kernel(f"[round 5 layout] row pass N={N} E={rE} T={N // rE}", N, rE, 1, True)
+        out[("column", N)] = x_kernel(f"[round 5 layout] column pass N={N} E={cE} T={N // cE} W={cW}", N, cE, cW, False)
+    return out
 
 
 if __name__ == "__main__":
