@@ -12,7 +12,8 @@ typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
 // row pass: 256 threads = rows p and N - p, thread t of 128 per row holds x = t + 128 s (MODE 0) or four consecutive x in each half of the row (MODE 1)
 template<int MODE>
-__global__ void __launch_bounds__(256) rowskel(float2 const* __restrict__ h0, float* __restrict__ phase, float const* __restrict__ omega, float4* __restrict__ spec, float const* __restrict__ omegawide) {
+__global__ void __launch_bounds__(256) rowskel(float2 const* __restrict__ h0, float* __restrict__ phase, float const* __restrict__ omega, float4* __restrict__ spec, float const* __restrict__ omegawide, int delay = 0) {
+  extern __shared__ unsigned char occupancy_cap[];      // (dynamic LDS of the launch: caps the workgroups per CU, nothing is stored there)
   constexpr int T = 128, E = 8;
   int const item = blockIdx.x; int const c = item / (N / 2), q = item % (N / 2); int const p = (q & 7) * (N / 16) + (q >> 3);       // the kernel's XCD bands
   int const half = threadIdx.x / T, t = threadIdx.x % T; int const y = half ? (p == 0 ? N / 2 : N - p) : p;
@@ -43,6 +44,8 @@ __global__ void __launch_bounds__(256) rowskel(float2 const* __restrict__ h0, fl
       u4 d = { __float_as_uint(ph[4*j] + om[4*j]), __float_as_uint(ph[4*j+1] + om[4*j+1]), __float_as_uint(ph[4*j+2] + om[4*j+2]), __float_as_uint(ph[4*j+3] + om[4*j+3]) };
       __builtin_amdgcn_raw_buffer_store_b128(d, rph, (y * N + x0) * 4, 0, PHASE_STORE_AUX); }
   }
+  // the kernel's arithmetic between its loads and its spectrum stores, as idle time: `delay` x 0.43 us (s_sleep 16 = 1024 clocks) once the inputs are there
+  if (delay > 0) { float keep = ph[0] + ph[E - 1] + a[0].x + b[E - 1].y + om[E - 1]; asm volatile("s_waitcnt vmcnt(0)" :: "v"(keep) : "memory"); for (int d = 0; d < delay; ++d) __builtin_amdgcn_s_sleep(16); }
   #pragma unroll
   for (int s = 0; s < E; ++s) { int x = t + T * s;
     u4 d = { __float_as_uint(a[s].x + b[s].x), __float_as_uint(a[s].y - b[s].y), __float_as_uint(ph[s]), __float_as_uint(om[s]) };
@@ -75,6 +78,9 @@ int main() {
     timeit("row pass skeleton (32 B/pt by design), the kernel's 4- and 8-byte loads", 32.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C), dim3(256), 0, 0, h0, phase, omega, spec, omegawide); });
     timeit("row pass skeleton, 16-byte loads and phase stores instead", 32.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<1>, dim3(N/2*C), dim3(256), 0, 0, h0, phase, omega, spec, omegawide); });
     timeit("column pass skeleton (40 B/pt)", 40.0*C*plane, [&]{ hipLaunchKernelGGL(colskel, dim3(N/4*C), dim3(256), 0, 0, spec, maps); });
+    for (int wgs : {8, 6, 4}) for (int delay : {0, 6, 12}) { char name[160]; snprintf(name, sizeof(name), "row pass skeleton, %d workgroups per CU, %.1f us idle between loads and spectrum stores", wgs, delay * 0.427);
+      size_t lds = wgs == 8 ? 0 : (size_t)(160 * 1024 / wgs) - 512; hipFuncSetAttribute(reinterpret_cast<void const*>(&rowskel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+      timeit(name, 32.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C), dim3(256), lds, 0, h0, phase, omega, spec, omegawide, delay); }); }
     timeit("both, back to back (72 B/pt: the step)", 72.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C), dim3(256), 0, 0, h0, phase, omega, spec, omegawide); hipLaunchKernelGGL(colskel, dim3(N/4*C), dim3(256), 0, 0, spec, maps); });
   }
   return 0;
