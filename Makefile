@@ -5,7 +5,7 @@ HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-f
 
 LIB = datum_amd/lib/libdatum_ocean_hip.so
 SRC = datum_amd/csrc/ocean_capi.hip
-DEPS = datum_amd/csrc/ocean_kernels.hip datum_amd/csrc/ocean_gen.hip datum_amd/csrc/ocean_farm.hip datum_amd/csrc/ocean_fft_core.h include/datum_ocean_hip.h
+DEPS = datum_amd/csrc/ocean_kernels.hip datum_amd/csrc/ocean_literal.hip datum_amd/csrc/ocean_gen.hip datum_amd/csrc/ocean_farm.hip datum_amd/csrc/ocean_fft_core.h include/datum_ocean_hip.h
 
 HOSTLIB = datum_amd/lib/libdatum_ocean_host.so
 HOSTSRC = datum_amd/host/ocean.cpp datum_amd/host/host_capi.cpp

@@ -104,6 +104,7 @@ SYMBOLS = {
     "datum_ocean_profile_end": (I, [P, ctypes.POINTER(D), ctypes.POINTER(D), ctypes.POINTER(I)]),
     "datum_ocean_algorithmic_bytes": (I, [P, ctypes.POINTER(D), ctypes.POINTER(D)]),
     "datum_ocean_abi_version": (I, []),
+    "datum_ocean_set_literal_transform": (I, [P, I]),
     "datum_ocean_export_maps": (I, [P, I, P, ctypes.c_size_t]),
 }
 
@@ -387,6 +388,10 @@ class Ocean:
         row, col, n = D(), D(), I()
         self._check(self.lib.datum_ocean_profile_end(self.h, ctypes.byref(row), ctypes.byref(col), ctypes.byref(n)))
         return row.value, col.value, n.value
+
+    def set_literal_transform(self, on):
+        """validation mode: displace through the reference's radix-2 transforms and literal twiddle table (datum_ocean_set_literal_transform)"""
+        self._check(self.lib.datum_ocean_set_literal_transform(self.h, 1 if on else 0))
 
     def export_maps(self, cascade, device_ptr, nbytes):
         """the cascade's maps as the reference's [layer][y][x][4] RGBA32F image, into DEVICE memory (datum_ocean_export_maps)"""

@@ -16,6 +16,7 @@
 
 #include "ocean_kernels.hip"
 #include "ocean_gen.hip"
+#include "ocean_literal.hip"
 #include "ocean_farm.hip"
 
 using namespace ocean;
@@ -36,6 +37,11 @@ struct datum_ocean_ctx
   float *phase = nullptr;
   void *spec = nullptr;               // cd[cascades][P], or ch[...] with the fp16 spectrum
   bool half = false;                  // DATUM_OCEAN_SPECTRUM_FP16
+
+  // validation mode (datum_ocean_set_literal_transform): the reference's own radix-2 transforms with its literal twiddle table
+  bool literal = false;
+  float2 *litfields = nullptr;        // [3][N*N]: h, hx, hy of the cascade being displaced (the reference's Spectrum buffer, ocean.cpp:61-68)
+  float *litweights = nullptr;        // [N][2 log2 N] (ocean.cpp:686-700)
   bool scaledirty[DATUM_OCEAN_MAX_CASCADES] = {};   // fp16 only: h0 changed since specscale was sized
   unsigned int *absmax = nullptr;     // device word for ocean_absmax_kernel
   float4 *maps = nullptr;             // the one in use
@@ -567,6 +573,8 @@ int datum_ocean_destroy(datum_ocean_t ctx)
   (void)hipFree(ctx->ownmaps);
   (void)hipFree(ctx->tw);
   (void)hipFree(ctx->omega);
+  (void)hipFree(ctx->litfields);
+  (void)hipFree(ctx->litweights);
   (void)hipFree(ctx->scratch);
 
   if (ctx->ownstream)
@@ -936,11 +944,36 @@ int datum_ocean_displace(datum_ocean_t ctx)
     rc = ensure_omega(ctx);
 
     if (rc == DATUM_OCEAN_OK)
-      rc = flush_pending(ctx, fusable(ctx) ? MAX_PENDING : 0);
+      rc = flush_pending(ctx, (fusable(ctx) && !ctx->literal) ? MAX_PENDING : 0);
   }
 
   if (rc != DATUM_OCEAN_OK)
     return rc;
+
+  if (ctx->literal)
+  {
+    // the reference's five dispatches, cascade by cascade (ocean.cpp:769-789); the phase was advanced by the general kernel above
+    size_t const P = plane(ctx);
+
+    for(int c = 0; c < ctx->cascades; ++c)
+    {
+      LiteralArgs a;
+      a.h0 = ctx->h0 + c * P;
+      a.phase = ctx->phase + c * P;
+      a.h = ctx->litfields;
+      a.hx = ctx->litfields + P;
+      a.hy = ctx->litfields + 2 * P;
+      a.weights = ctx->litweights;
+      a.maps = reinterpret_cast<char*>(ctx->maps) + (size_t)c * map_cascade_bytes(ctx->N);
+      a.N = ctx->N;
+      a.scale = ctx->casc[c].scale;
+      a.choppiness = ctx->casc[c].choppiness;
+
+      HIPCHECK(ctx, launch_literal(a, ctx->stream));
+    }
+
+    return DATUM_OCEAN_OK;
+  }
 
   rc = size_spectrum_scale(ctx);
   if (rc != DATUM_OCEAN_OK)
@@ -1411,6 +1444,39 @@ int datum_ocean_export_maps(datum_ocean_t ctx, int cascade, void *device_dst, si
                      reinterpret_cast<char const*>(ctx->maps) + (size_t)cascade * map_cascade_bytes(ctx->N), ctx->N, static_cast<float4*>(device_dst));
 
   HIPCHECK(ctx, hipGetLastError());
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_set_literal_transform(datum_ocean_t ctx, int on)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_set_literal_transform: null handle");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  if (on && !ctx->litfields)
+  {
+    size_t const P = plane(ctx);
+
+    int stages = 0;
+    while ((1 << stages) < ctx->N)
+      ++stages;
+
+    std::vector<float> weights;
+    try { weights.resize((size_t)ctx->N * 2 * stages); } catch (...) { return fail(ctx, DATUM_OCEAN_ENOMEM, "datum_ocean_set_literal_transform: out of host memory"); }
+
+    int rc = datum_ocean_reference_weights(ctx->N, weights.data());
+    if (rc != DATUM_OCEAN_OK)
+      return rc;
+
+    HIPCHECK(ctx, hipMalloc(&ctx->litweights, weights.size() * sizeof(float)));
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->litweights, weights.data(), weights.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));       // (the host vector goes out of scope)
+    HIPCHECK(ctx, hipMalloc(&ctx->litfields, 3 * P * sizeof(float2)));
+  }
+
+  ctx->literal = on != 0;
 
   return DATUM_OCEAN_OK;
 }

@@ -741,6 +741,9 @@ bool prepare_ocean_context(DatumPlatform::PlatformInterface &platform, OceanCont
   if (context.spectrumfp16)
     check(context.hip, datum_ocean_set_spectrum_format(context.hip, DATUM_OCEAN_SPECTRUM_FP16), "datum_ocean_set_spectrum_format");
 
+  if (context.literaltransform)
+    check(context.hip, datum_ocean_set_literal_transform(context.hip, 1), "datum_ocean_set_literal_transform");
+
   context.ready = true;
 
   return true;

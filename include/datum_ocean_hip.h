@@ -38,7 +38,7 @@ extern "C" {
  * libdatum_ocean_hip.so is refused instead of misread.
  *   3  round 3: ENOTREADY = +1, datum_ocean_map_layout with four arguments, 32-byte texels
  *   4  round 4: ENOTREADY = -5, datum_ocean_map_layout gained texel_bytes, 24-byte texels in bound map buffers, farm entry points
- *   5  round 5: datum_ocean_abi_version, datum_ocean_export_maps */
+ *   5  round 5: datum_ocean_abi_version, datum_ocean_export_maps, datum_ocean_set_literal_transform */
 #define DATUM_OCEAN_ABI_VERSION 5
 int datum_ocean_abi_version(void);
 
@@ -122,6 +122,15 @@ int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, flo
 #define DATUM_OCEAN_SPECTRUM_FP32 0
 #define DATUM_OCEAN_SPECTRUM_FP16 1
 int datum_ocean_set_spectrum_format(datum_ocean_t ctx, int format);
+
+/* VALIDATION MODE (round 5): displace through the reference's own algorithm instead of the fused kernels -- ocean.sim, log2 N
+ * radix-2 Stockham stages along rows and along columns with the LITERAL twiddle table of ocean.cpp:686-700 (cos / sin of unreduced
+ * fp32 angles, datum_ocean_reference_weights), ocean.map -- the same operations in the same order as data/ocean.{sim,fftx,ffty,map}.comp,
+ * one thread per point.  For comparing a HIP frame with a frame of the Vulkan build texel for texel: the fused path differs from the
+ * literal arithmetic by that table's own error (RMSE 1.4e-5 at 1024^2, 7e-5 at 4096^2; it is the one closer to a float64 transform).
+ * 4-17 x slower than the fused step (tools/literal_bench.py), 24 * N * N bytes of extra device memory once switched on; phase, maps, gen, read_maps,
+ * export_maps and the farm work as before.  Takes effect at the next datum_ocean_displace. */
+int datum_ocean_set_literal_transform(datum_ocean_t ctx, int on);
 
 int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, float const *phase);
 int datum_ocean_read_state(datum_ocean_t ctx, int cascade, float *phase);
