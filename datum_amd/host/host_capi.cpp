@@ -183,8 +183,8 @@ extern "C"
     catch(std::exception const &e) { return caught(e); }
   }
 
-  // initialise_ocean_context + prepare_ocean_context (examples/ocean/ocean.cpp:31,165)
-  void *datum_host_context_create(int device, int resolution)
+  // initialise_ocean_context + prepare_ocean_context (examples/ocean/ocean.cpp:31,165); flags: 1 = OceanContext::spectrumfp16, 2 = ::literaltransform
+  void *datum_host_context_create_ex(int device, int resolution, int flags)
   {
     HostContext *hc = nullptr;
 
@@ -193,6 +193,8 @@ extern "C"
       hc = new HostContext;
       hc->platform.hipdevice = device;
       hc->context.resolution = resolution;
+      hc->context.spectrumfp16 = (flags & 1) != 0;
+      hc->context.literaltransform = (flags & 2) != 0;
 
       initialise_ocean_context(hc->platform, hc->context, 0);
 
@@ -208,6 +210,8 @@ extern "C"
       return nullptr;
     }
   }
+
+  void *datum_host_context_create(int device, int resolution) { return datum_host_context_create_ex(device, resolution, 0); }
 
   void datum_host_context_destroy(void *c) { delete static_cast<HostContext*>(c); }
 

@@ -155,6 +155,35 @@ def test_render_through_host_api_and_wave_change(oracle):
         assert np.array_equal(idx, oracle.indices(32, 48))
 
 
+def test_the_reference_configuration_in_literal_mode_against_the_golden_maps(oracle):
+    # The reference as shipped: WaveResolution 64, example-ocean parameters, seed 1000, dt = 1/60 -- through the C++ mirror of datum's API with
+    # OceanContext::literaltransform (the reference's own radix-2 transforms and literal twiddle table on the GPU): the golden maps of
+    # tests/golden/ocean_n64.npz (the oracle with that same table) after 60 and after 600 ticks, to fp32 rounding
+    from datum_amd import host_api
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ocean_n64.npz"))
+    N = 64
+    p = host_api.OceanParams(N, **host_api.EXAMPLE_TUNABLES)
+    p.seed_ocean(1000)
+    assert np.array_equal(p.height, g["h0"])
+    with host_api.OceanContext(N, literaltransform=True) as lit, host_api.OceanContext(N) as fused:
+        mesh, mesh2 = lit.create_ocean(32, 32), fused.create_ocean(32, 32)
+        done = 0
+        for ticks in (60, 600):
+            while done < ticks:
+                p.update_ocean(DT)
+                done += 1
+            lit.render_ocean_surface(mesh, p)
+            fused.render_ocean_surface(mesh2, p)
+            m, mf = lit.read_displacement(), fused.read_displacement()
+            want = g[f"maps_{ticks}"]
+            e_lit, e_fused = rmse(m[..., :3], want[..., :3]), rmse(mf[..., :3], want[..., :3])
+            assert e_lit < 1e-7 and e_lit < e_fused < 1e-5, (ticks, e_lit, e_fused)
+            assert float(np.abs(m[..., :3].astype(np.float64) - want[..., :3]).max()) < 5e-7
+        lit.fetch_ocean_state(p)
+        assert np.array_equal(p.phase, g["phase_600"])
+
+
 def test_device_side_spectrum_rebuild(oracle):
     # lerp_ocean_waves' h0 rebuild on the device from the resident seed.
     # Tolerance: expf / division differ from libm by ulps -> 2e-6 relative to the largest |h0| (and exact zeros
