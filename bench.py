@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--standin-workgroups", type=int, default=32,
                     help="--standin-peers: workgroups of the stand-in kernel on the second stream (RCCL's channels are workgroups that copy); "
                          "0 = device-to-device copies, which occupy no compute unit")
+    ap.add_argument("--comm-cus", type=int, default=-1,
+                    help="compute units reserved for the communication stream (a multiple of 8: that many / 8 per XCD), the step's stream on the "
+                         "others (datum_ocean_farm_partition); 0: both streams on the whole device.  Default: 32 where a collective (or its "
+                         "stand-in) runs under the steps, else 0")
     ap.add_argument("--standin-gbps", type=float, default=300.0,
                     help="--standin-peers: bus bandwidth the stand-in is paced to (0 = as fast as HBM takes it)")
     ap.add_argument("--plumbing", action="store_true",
@@ -389,7 +393,13 @@ def main():
     maps = torch.empty(C * capi.map_block_floats(N), dtype=torch.float32, device=dev)
     oc.bind_maps(maps.data_ptr(), maps.numel() * 4)
     # a real (non-default) stream: events and RCCL below are ordered on it too (DATUM_COMPUTE_PRIORITY: tools/gather_overhead.sh, -1 = high)
-    stream = torch.cuda.Stream(dev, priority=int(os.environ["DATUM_COMPUTE_PRIORITY"])) if "DATUM_COMPUTE_PRIORITY" in os.environ else torch.cuda.Stream(dev)
+    # (DATUM_COMPUTE_CUMASK: the step on a subset of the compute units, the stand-in's stream on the others: tools/gather_overhead_cumask.sh)
+    if "DATUM_COMPUTE_CUMASK" in os.environ:
+        from datum_amd.farm import cu_masked_stream
+
+        stream = cu_masked_stream(dev, int(os.environ["DATUM_COMPUTE_CUMASK"], 16))
+    else:
+        stream = torch.cuda.Stream(dev, priority=int(os.environ["DATUM_COMPUTE_PRIORITY"])) if "DATUM_COMPUTE_PRIORITY" in os.environ else torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     oc.set_stream(stream.cuda_stream)
     # the all-gather of north_star.  N > 1 (or --force-collective): the module's own farm (datum_ocean_farm_*: RCCL communicator,
@@ -403,14 +413,30 @@ def main():
         code, pdtype, _ = farm.PAYLOADS[args.payload]
         pbytes = oc.payload_bytes(code)
         assert pbytes == farm.payload_bytes(N, C, args.payload)
+    # the collective's workgroups and the step's on disjoint compute units (include/datum_ocean_hip.h: datum_ocean_farm_partition)
+    comm_cus = args.comm_cus if args.comm_cus >= 0 else (32 if (gathering and args.gather == "pipelined" and "DATUM_COMM_CUMASK" not in os.environ and "DATUM_COMPUTE_CUMASK" not in os.environ) else 0)
+    if not gathering:
+        comm_cus = 0
     if native:
         box = [capi.farm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         oc.farm_init(box[0], rank, world, code, slots=2)
         farm_info = oc.farm_info()
+        if comm_cus:
+            # the module recreates its two streams; the steps, the events and the consumers below move to its (masked) own stream
+            oc.farm_partition(comm_cus)
+            stream = torch.cuda.ExternalStream(oc.own_stream(), device=dev)
+            torch.cuda.set_stream(stream)
+            oc.set_stream(None)
     elif gathering:
+        if comm_cus:
+            total = torch.cuda.get_device_properties(dev).multi_processor_count
+            stream = farm.cu_masked_stream(dev, ((1 << total) - 1) ^ ((1 << comm_cus) - 1))
+            torch.cuda.set_stream(stream)
+            oc.set_stream(stream.cuda_stream)
         tg = farm.TileGather(farm.payload_numel(N, C, args.payload), pdtype, dev, world, standin_peers=args.standin_peers,
-                             force_collective=args.force_collective, standin_workgroups=args.standin_workgroups, standin_gbps=args.standin_gbps)
+                             force_collective=args.force_collective, standin_workgroups=args.standin_workgroups, standin_gbps=args.standin_gbps,
+                             comm_cus=comm_cus)
 
     def step():
         oc.update(DT)
@@ -677,6 +703,7 @@ def main():
                 "collective_backend": (None if not (multi and gathering) else (f"RCCL {farm_info['rccl_version']} through the module's C ABI (datum_ocean_farm_*), {farm_info['slots']} slots" if native
                                                                               else "RCCL through torch.distributed (datum_amd/farm.py)")),
                 "measured_on_hardware": ("this line" if world > 1 else "1 GPU"),
+                "cu_partition": ({"communication_stream_cus": comm_cus, "compute_stream_cus": torch.cuda.get_device_properties(dev).multi_processor_count - comm_cus} if comm_cus else None),
                 "payload": args.payload if gathering else None,
                 "payload_bytes_per_rank": pbytes if gathering else None,
                 "parallelism": f"tile-farm x{world}",

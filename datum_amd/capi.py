@@ -80,6 +80,8 @@ SYMBOLS = {
     "datum_ocean_farm_release": (I, [P, I, P, I]),
     "datum_ocean_farm_query": (I, [P, I]),
     "datum_ocean_farm_wait": (I, [P, I, ctypes.POINTER(F)]),
+    "datum_ocean_farm_partition": (I, [P, I]),
+    "datum_ocean_own_stream": (I, [P, ctypes.POINTER(P)]),
     "datum_ocean_read_maps": (I, [P, I, P]),
     "datum_ocean_sync": (I, [P]),
     "datum_ocean_wait_event": (I, [P, P]),
@@ -303,6 +305,16 @@ class Ocean:
             return False
         self._check(rc)
         return True
+
+    def farm_partition(self, comm_cus):
+        """The communication stream on `comm_cus` compute units of its own (comm_cus / 8 per XCD), the handle's own stream on the others; 0 undoes it."""
+        self._check(self.lib.datum_ocean_farm_partition(self.h, comm_cus))
+
+    def own_stream(self):
+        """The handle's own hipStream_t as an integer (torch.cuda.ExternalStream takes it)."""
+        p = P()
+        self._check(self.lib.datum_ocean_own_stream(self.h, ctypes.byref(p)))
+        return p.value
 
     def farm_wait(self, slot):
         """Host wait for the slot's collective; returns its duration on the communication stream in ms."""

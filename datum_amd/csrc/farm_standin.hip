@@ -145,6 +145,36 @@ namespace
   }
 }
 
+// where the workgroups of a launch on `stream` ran: out[2 g] = XCC_ID, out[2 g + 1] = HW_ID of workgroup g (which compute units a
+// CU-masked stream really covers: tools/cumask_probe.py)
+namespace
+{
+  __global__ void __launch_bounds__(THREADS) where_kernel(unsigned *out)
+  {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+
+    // long enough that the launch spreads over every compute unit it may use
+    unsigned long long const t0 = realtime();
+    while (realtime() < t0 + 2000)
+      __builtin_amdgcn_s_sleep(8);
+
+    if (threadIdx.x == 0)
+    {
+      out[2 * blockIdx.x] = xcc;
+      out[2 * blockIdx.x + 1] = hw;
+    }
+  }
+}
+
+extern "C" int datum_farm_standin_where(unsigned *out, int workgroups, void *stream)
+{
+  hipLaunchKernelGGL(where_kernel, dim3(workgroups), dim3(THREADS), 0, (hipStream_t)stream, out);
+
+  return (int)hipGetLastError();
+}
+
 // bytes: a multiple of 16.  gbps: the bus bandwidth the copy is paced to (bytes * peers / duration), 0 = as fast as it goes.
 extern "C" int datum_farm_standin_gather_mode(void *gathered, void const *payload, size_t bytes, int peers, int workgroups, double gbps, int mode, void *stream);
 

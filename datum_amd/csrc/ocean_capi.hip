@@ -434,6 +434,25 @@ namespace
     if (f->stream)
       (void)hipStreamDestroy(f->stream);
 
+    // datum_ocean_farm_partition had confined the handle's own stream to the compute units the collective left it: all of them again
+    if (f->commcus && ctx->ownstream)
+    {
+      hipStream_t whole = nullptr;
+
+      (void)hipStreamSynchronize(ctx->ownstream);
+
+      if (hipStreamCreateWithFlags(&whole, hipStreamNonBlocking) == hipSuccess)
+      {
+        bool const onown = ctx->stream == ctx->ownstream;
+
+        (void)hipStreamDestroy(ctx->ownstream);
+        ctx->ownstream = whole;
+
+        if (onown)
+          ctx->stream = whole;
+      }
+    }
+
     delete f;
 
     ctx->farm = nullptr;
@@ -1363,6 +1382,81 @@ int datum_ocean_farm_wait(datum_ocean_t ctx, int slot, float *collective_ms)
 
   if (collective_ms)
     HIPCHECK(ctx, hipEventElapsedTime(collective_ms, sl->start, sl->done));
+
+  return DATUM_OCEAN_OK;
+}
+
+namespace
+{
+  // a stream on the compute units [first, first + count) of the device's CU-mask order (bit i: CU i / 8 of XCD i % 8 on an MI355X,
+  // tools/cumask_probe.py); count == 0: an ordinary stream
+  hipError_t make_stream(hipStream_t *stream, int cus, int first, int count)
+  {
+    if (count == 0)
+      return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+
+    std::vector<uint32_t> words((cus + 31) / 32, 0u);
+
+    for(int i = first; i < first + count; ++i)
+      words[i / 32] |= 1u << (i % 32);
+
+    return hipExtStreamCreateWithCUMask(stream, (uint32_t)words.size(), words.data());
+  }
+}
+
+int datum_ocean_farm_partition(datum_ocean_t ctx, int comm_cus)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_farm_partition: null handle");
+
+  Farm *f = ctx->farm;
+
+  if (!f)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_farm_partition: the handle does not farm (datum_ocean_farm_init first)");
+
+  if (comm_cus < 0 || comm_cus % 8 != 0 || comm_cus > ctx->cus / 2)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_farm_partition: comm_cus must be 0 or a multiple of 8 (one share per XCD), at most half the device");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  // nothing in flight on either stream while they are replaced (the slots' events stay valid: they have completed)
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->ownstream));
+  HIPCHECK(ctx, hipStreamSynchronize(f->stream));
+
+  hipStream_t comm = nullptr, own = nullptr;
+
+  HIPCHECK(ctx, make_stream(&comm, ctx->cus, 0, comm_cus));
+
+  hipError_t const e = make_stream(&own, ctx->cus, comm_cus, comm_cus ? ctx->cus - comm_cus : 0);
+
+  if (e != hipSuccess)
+  {
+    (void)hipStreamDestroy(comm);
+    return fail(ctx, (int)e, "datum_ocean_farm_partition: hipExtStreamCreateWithCUMask");
+  }
+
+  bool const onown = ctx->stream == ctx->ownstream;
+
+  (void)hipStreamDestroy(f->stream);
+  (void)hipStreamDestroy(ctx->ownstream);
+
+  f->stream = comm;
+  f->commcus = comm_cus;
+  ctx->ownstream = own;
+
+  if (onown)
+    ctx->stream = own;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_own_stream(datum_ocean_t ctx, void **hip_stream)
+{
+  if (!ctx || !hip_stream)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_own_stream: null argument");
+
+  *hip_stream = ctx->ownstream;
 
   return DATUM_OCEAN_OK;
 }

@@ -147,6 +147,7 @@ namespace ocean
     RcclApi *api = nullptr;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;     // the communication stream
+    int commcus = 0;                  // datum_ocean_farm_partition: the stream's compute units (0: all)
     int rank = 0, world = 1;
     int format = DATUM_OCEAN_PAYLOAD_XYZ32;
     size_t bytes = 0;                 // payload bytes per rank

@@ -90,6 +90,30 @@ def view_displacement(gathered, N, global_index, fmt):
     return gathered[global_index * n:(global_index + 1) * n].view(N, N, per)[..., :3]
 
 
+def cu_masked_stream(device, mask):
+    """A HIP stream whose kernels run only on the compute units whose bit is set in `mask` (hipExtStreamCreateWithCUMask; bit i of
+    the mask is CU i / 8 of XCD i % 8 on this part: tools/cumask_probe.py), as a torch stream.  Keeping the collective's copying
+    workgroups and the step's workgroups on DIFFERENT compute units takes the collective's bursts out of the in-order memory queues
+    the step's workgroups wait in (profiles/r05_gather_overhead.txt)."""
+    import ctypes
+
+    hip = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64.so" in line:
+                hip = ctypes.CDLL(line.split()[-1])
+                break
+    if hip is None:
+        raise RuntimeError("cu_masked_stream: libamdhip64 is not loaded (no HIP device initialised?)")
+    words = (ctypes.c_uint32 * 8)(*[(mask >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), 8, words)
+    if rc != 0 or not handle.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask: {rc}")
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
 class TileGather:
     """Double-buffered, overlapped all-gather of the ranks' payloads.
 
@@ -110,7 +134,7 @@ class TileGather:
     returns the payload itself.
     """
 
-    def __init__(self, numel, dtype, device, world, slots=2, standin_peers=0, force_collective=False, standin_workgroups=32, standin_gbps=0.0):
+    def __init__(self, numel, dtype, device, world, slots=2, standin_peers=0, force_collective=False, standin_workgroups=32, standin_gbps=0.0, comm_cus=0):
         # standin_peers (measurement aid, one GPU only): in place of the collective, the communication stream runs a kernel of
         # `standin_workgroups` workgroups (RCCL's channels are workgroups that copy) that writes the payload `standin_peers`
         # times into the gathered buffer -- the HBM writes of that many peers' tiles arriving -- paced to `standin_gbps` of
@@ -150,7 +174,12 @@ class TileGather:
         self.pending = []                    # launched, not yet handed out by result()
         if self.cuda:
             # (DATUM_COMM_PRIORITY: tools/gather_overhead.sh -- the communication stream below the compute stream)
-            self.comm = torch.cuda.Stream(self.device, priority=int(os.environ.get("DATUM_COMM_PRIORITY", "0"))) if "DATUM_COMM_PRIORITY" in os.environ else torch.cuda.Stream(self.device)
+            # (DATUM_COMM_CUMASK: the communication stream on its own compute units)
+            # comm_cus: the communication stream on that many compute units of its own, the low bits of the device's CU mask
+            if comm_cus or "DATUM_COMM_CUMASK" in os.environ:
+                self.comm = cu_masked_stream(self.device, (1 << comm_cus) - 1 if comm_cus else int(os.environ["DATUM_COMM_CUMASK"], 16))
+            else:
+                self.comm = torch.cuda.Stream(self.device, priority=int(os.environ.get("DATUM_COMM_PRIORITY", "0"))) if "DATUM_COMM_PRIORITY" in os.environ else torch.cuda.Stream(self.device)
             self.packed = [torch.cuda.Event() for _ in range(slots)]
             self.timing = [None] * slots     # (start, stop) events around the slot's last collective
 

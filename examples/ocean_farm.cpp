@@ -4,7 +4,8 @@
 // all-gather per batch through the C ABI (datum_ocean_farm_*).  No Python, no PyTorch, no MPI: the parent starts the ranks
 // as child processes BEFORE anything touches a GPU and relays rank 0's 128-byte communicator id over pipes.
 //
-// Usage: ocean_farm [ranks=1] [resolution=2048] [batches=3] [steps_per_batch=20] [payload: 1 xyz32 | 2 xyz16 | 0 maps]
+// Usage: ocean_farm [ranks=1] [resolution=2048] [batches=3] [steps_per_batch=20] [payload: 1 xyz32 | 2 xyz16 | 0 maps] [comm_cus=32]
+// comm_cus: compute units the collective gets to itself (datum_ocean_farm_partition; 0 = both streams on the whole device)
 // Every rank prints one line per batch: a checksum of every tile of the gathered field (all ranks must print the same), and
 // whether its own tile in the gathered block equals what it packed.  Exit code 0 only if every rank succeeded.
 //
@@ -40,7 +41,7 @@ namespace
 
   #define CHECK(call) do { int rc_ = (call); if (rc_ != DATUM_OCEAN_OK) { fprintf(stderr, "rank %d: %s failed (%d): %s\n", rank, #call, rc_, datum_ocean_last_error(hip)); return 1; } } while(0)
 
-  int run_rank(int rank, int world, int idin, int idout, int N, int batches, int steps, int format)
+  int run_rank(int rank, int world, int idin, int idout, int N, int batches, int steps, int format, int commcus)
   {
     datum_ocean_t hip = nullptr;
 
@@ -79,6 +80,10 @@ namespace
     }
 
     CHECK(datum_ocean_farm_init(hip, id, sizeof(id), rank, world, format, 2));
+
+    // the collective's copying workgroups on compute units of their own, the step's kernels on the others
+    if (commcus > 0)
+      CHECK(datum_ocean_farm_partition(hip, commcus));
 
     size_t bytes = 0;
     CHECK(datum_ocean_payload_bytes(hip, format, &bytes));
@@ -158,6 +163,7 @@ int main(int argc, char **argv)
   int batches = (argc > 3) ? atoi(argv[3]) : 3;
   int steps = (argc > 4) ? atoi(argv[4]) : 20;
   int format = (argc > 5) ? atoi(argv[5]) : DATUM_OCEAN_PAYLOAD_XYZ32;
+  int commcus = (argc > 6) ? atoi(argv[6]) : 32;
 
   if (world < 1 || world > 64)
     return 2;
@@ -200,7 +206,7 @@ int main(int argc, char **argv)
           close(tochild[2 * k]);
       }
 
-      _exit(run_rank(r, world, r ? tochild[2 * r] : -1, r ? -1 : fromzero[1], N, batches, steps, format));
+      _exit(run_rank(r, world, r ? tochild[2 * r] : -1, r ? -1 : fromzero[1], N, batches, steps, format, commcus));
     }
   }
 

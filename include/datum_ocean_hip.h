@@ -38,8 +38,9 @@ extern "C" {
  * libdatum_ocean_hip.so is refused instead of misread.
  *   3  round 3: ENOTREADY = +1, datum_ocean_map_layout with four arguments, 32-byte texels
  *   4  round 4: ENOTREADY = -5, datum_ocean_map_layout gained texel_bytes, 24-byte texels in bound map buffers, farm entry points
- *   5  round 5: datum_ocean_abi_version, datum_ocean_export_maps, datum_ocean_set_literal_transform */
-#define DATUM_OCEAN_ABI_VERSION 5
+ *   5  round 5: datum_ocean_abi_version, datum_ocean_export_maps, datum_ocean_set_literal_transform
+ *   6  round 5: datum_ocean_farm_partition, datum_ocean_own_stream */
+#define DATUM_OCEAN_ABI_VERSION 6
 int datum_ocean_abi_version(void);
 
 enum
@@ -221,6 +222,19 @@ int datum_ocean_farm_result(datum_ocean_t ctx, int slot, void *hip_stream, int o
 int datum_ocean_farm_release(datum_ocean_t ctx, int slot, void *hip_stream, int on_handle_stream);
 int datum_ocean_farm_query(datum_ocean_t ctx, int slot);
 int datum_ocean_farm_wait(datum_ocean_t ctx, int slot, float *collective_ms);
+
+/* The farm's two streams on DISJOINT compute units (hipExtStreamCreateWithCUMask; ABI 6).  RCCL's channels are workgroups that copy; while
+ * they share compute units with the step's workgroups their bursts sit in the same in-order memory queues and the step kernels take 46-54 %
+ * longer under a collective-sized copy (one-GPU stand-in, profiles/r05_gather_overhead.txt); with the copy on 32 compute units of its own and
+ * the step on the other 224 it is 27-28 % (7 % of it the 32 CUs the step gives up).
+ *   partition   after farm_init, nothing in flight: comm_cus (0 = undo, else a multiple of 8, at most half the device) compute units --
+ *               comm_cus / 8 of each XCD -- for the communication stream, the others for the handle's OWN stream; both streams are
+ *               recreated.  A handle that runs on a caller's stream (datum_ocean_set_stream) keeps it: hand it the own stream instead
+ *   own_stream  the handle's own hipStream_t (e.g. to record events on it or to make it the current stream of a framework), valid until
+ *               the next partition / shutdown / destroy
+ * farm_shutdown undoes the partition. */
+int datum_ocean_farm_partition(datum_ocean_t ctx, int comm_cus);
+int datum_ocean_own_stream(datum_ocean_t ctx, void **hip_stream);
 
 /* blocking read-backs (host pointers).  maps: 2*N*N*4 floats. */
 int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps);

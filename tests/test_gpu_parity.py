@@ -1181,6 +1181,60 @@ def test_native_farm_one_rank(capi, oracle, torch):
             oc.set_stream(None)                                   # destroy tears the farm down
 
 
+def test_native_farm_on_partitioned_compute_units(capi, oracle, torch):
+    # datum_ocean_farm_partition: the communication stream on 32 compute units of its own, the handle's own stream on the other 224
+    # (hipExtStreamCreateWithCUMask).  Same results as the whole-device streams, batch for batch, with a real (one-rank) RCCL
+    # all-gather on the masked stream; the partition undone and redone between batches; refused without a farm / with a count that is
+    # not a multiple of 8 / above half the device; farm_shutdown gives the own stream the whole device back.
+    from datum_amd import farm
+
+    N, C, fmt = 256, 2, "xyz32"
+    p = oracle.EXAMPLE
+    code, dtype, per = farm.PAYLOADS[fmt]
+    numel = farm.payload_numel(N, C, fmt)
+
+    def batches(partition):
+        out = []
+        with capi.Ocean(N, C) as oc:
+            for c in range(C):
+                oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c], p["choppiness"])
+                oc.upload_state(c, make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c]))
+            with pytest.raises(capi.OceanError) as e:
+                oc.farm_partition(32)                             # no farm yet
+            assert e.value.code == capi.ESTATE
+            oc.farm_init(capi.farm_unique_id(), 0, 1, code, slots=2)
+            before = oc.own_stream()
+            assert before
+            for bad in (-8, 12, 136):
+                with pytest.raises(capi.OceanError) as e:
+                    oc.farm_partition(bad)
+                assert e.value.code == capi.EINVAL
+            for b in range(6):
+                if partition:
+                    oc.farm_partition(partition[b % len(partition)])
+                # the handle runs on its own stream: a framework takes it from the module
+                with torch.cuda.stream(torch.cuda.ExternalStream(oc.own_stream(), device="cuda:0")):
+                    for _ in range(3):
+                        oc.update(DT)
+                        oc.displace()
+                    slot = oc.farm_gather()
+                    ptr, n = oc.farm_result(slot)
+                    out.append(_device_view(torch, ptr, numel, dtype).clone())
+                    oc.sync()
+            oc.farm_shutdown()
+            oc.update(DT)
+            oc.displace()                                         # the own stream is whole (and alive) again
+            out.append(torch.from_numpy(oc.read_maps(0)))
+        return out
+
+    plain = batches(None)
+    for pattern in ([32], [32, 0, 64, 8]):
+        got = batches(pattern)
+        assert len(got) == len(plain)
+        for b, (x, y) in enumerate(zip(got, plain)):
+            assert torch.equal(x.cpu(), y.cpu()), (pattern, b)
+
+
 def _device_view(torch, ptr, numel, dtype):
     """A torch tensor over device memory the module owns (no copy): __cuda_array_interface__ of a raw pointer."""
 

@@ -5,7 +5,7 @@
 #   modes: 0 copy, 1 resident only, 2 reads only, 3 writes only, 7 copy with the destination wrapped into one peer's share (same bytes, 1/7 of the
 #   footprint), 8 writes only, wrapped
 STEPS=${STEPS:-20}; WARM=${WARM:-5}
-run() { python bench.py --steps $STEPS --warmup $WARM --cpu-seconds 0 --no-frame --no-regime "$@" 2>/dev/null | python3 -c '
+run() { python bench.py --steps $STEPS --warmup $WARM --cpu-seconds 0 --no-frame --no-regime --comm-cus 0 "$@" 2>/dev/null | python3 -c '
 import json,sys
 for l in sys.stdin:
     if l.startswith("{"):
