@@ -34,10 +34,13 @@ namespace
 
   __global__ void __launch_bounds__(THREADS) standin_kernel(uint4 *dst, uint4 const *src, size_t bytes, int peers, float ticks_per_chunk, int mode)
   {
+    // mode 9: as 0 with source AND destination wrapped into 2 MB -- the same bytes through the compute units' memory paths, nothing
+    // displaced in the 256 MiB Infinity Cache: what of the slowdown is the cache, what the paths (profiles/r05_gather_overhead.txt)
+    bool const tiny = mode == 9;
     bool const wrap = mode >= 7;
 
     if (wrap)
-      mode = (mode == 7) ? 0 : 3;
+      mode = (mode == 8) ? 3 : 0;
 
     bool const nt = mode >= 4;
 
@@ -51,7 +54,7 @@ namespace
 
     for(size_t item = blockIdx.x; item < total; item += gridDim.x)
     {
-      size_t const peer = wrap ? 0 : item / chunks, chunk = item % chunks;
+      size_t const peer = wrap ? 0 : item / chunks, chunk = tiny ? (item % chunks) % 64 : item % chunks;
       size_t const first = chunk * (CHUNK / 16), last = min((chunk + 1) * (CHUNK / 16), bytes / 16);
 
       if (last - first == CHUNK / 16 && mode != 1)

@@ -90,6 +90,16 @@ def view_displacement(gathered, N, global_index, fmt):
     return gathered[global_index * n:(global_index + 1) * n].view(N, N, per)[..., :3]
 
 
+def _hip():
+    import ctypes
+
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64.so" in line:
+                return ctypes.CDLL(line.split()[-1])
+    raise RuntimeError("libamdhip64 is not loaded (no HIP device initialised?)")
+
+
 def cu_masked_stream(device, mask):
     """A HIP stream whose kernels run only on the compute units whose bit is set in `mask` (hipExtStreamCreateWithCUMask; bit i of
     the mask is CU i / 8 of XCD i % 8 on this part: tools/cumask_probe.py), as a torch stream.  Keeping the collective's copying
@@ -97,14 +107,7 @@ def cu_masked_stream(device, mask):
     the step's workgroups wait in (profiles/r05_gather_overhead.txt)."""
     import ctypes
 
-    hip = None
-    with open("/proc/self/maps") as f:
-        for line in f:
-            if "libamdhip64.so" in line:
-                hip = ctypes.CDLL(line.split()[-1])
-                break
-    if hip is None:
-        raise RuntimeError("cu_masked_stream: libamdhip64 is not loaded (no HIP device initialised?)")
+    hip = _hip()
     words = (ctypes.c_uint32 * 8)(*[(mask >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
     handle = ctypes.c_void_p()
     with torch.cuda.device(device):
