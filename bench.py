@@ -414,7 +414,9 @@ def main():
         pbytes = oc.payload_bytes(code)
         assert pbytes == farm.payload_bytes(N, C, args.payload)
     # the collective's workgroups and the step's on disjoint compute units (include/datum_ocean_hip.h: datum_ocean_farm_partition)
-    comm_cus = args.comm_cus if args.comm_cus >= 0 else (32 if (gathering and args.gather == "pipelined" and "DATUM_COMM_CUMASK" not in os.environ and "DATUM_COMPUTE_CUMASK" not in os.environ) else 0)
+    # (default: an eighth of the device in whole shares of 8 -- 32 of an MI355X's 256)
+    device_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    comm_cus = args.comm_cus if args.comm_cus >= 0 else ((device_cus // 64) * 8 if (gathering and args.gather == "pipelined" and "DATUM_COMM_CUMASK" not in os.environ and "DATUM_COMPUTE_CUMASK" not in os.environ) else 0)
     if not gathering:
         comm_cus = 0
     if native:
@@ -424,14 +426,19 @@ def main():
         farm_info = oc.farm_info()
         if comm_cus:
             # the module recreates its two streams; the steps, the events and the consumers below move to its (masked) own stream
-            oc.farm_partition(comm_cus)
-            stream = torch.cuda.ExternalStream(oc.own_stream(), device=dev)
-            torch.cuda.set_stream(stream)
-            oc.set_stream(None)
+            try:
+                oc.farm_partition(comm_cus)
+            except capi.OceanError as e:
+                # (a runtime without CU masks: the farm works without the partition)
+                print(f"bench.py: rank {rank}: datum_ocean_farm_partition({comm_cus}) refused, both streams on the whole device: {e}", file=sys.stderr)
+                comm_cus = 0
+            else:
+                stream = torch.cuda.ExternalStream(oc.own_stream(), device=dev)
+                torch.cuda.set_stream(stream)
+                oc.set_stream(None)
     elif gathering:
         if comm_cus:
-            total = torch.cuda.get_device_properties(dev).multi_processor_count
-            stream = farm.cu_masked_stream(dev, ((1 << total) - 1) ^ ((1 << comm_cus) - 1))
+            stream = farm.cu_masked_stream(dev, ((1 << device_cus) - 1) ^ ((1 << comm_cus) - 1))
             torch.cuda.set_stream(stream)
             oc.set_stream(stream.cuda_stream)
         tg = farm.TileGather(farm.payload_numel(N, C, args.payload), pdtype, dev, world, standin_peers=args.standin_peers,
@@ -703,7 +710,7 @@ def main():
                 "collective_backend": (None if not (multi and gathering) else (f"RCCL {farm_info['rccl_version']} through the module's C ABI (datum_ocean_farm_*), {farm_info['slots']} slots" if native
                                                                               else "RCCL through torch.distributed (datum_amd/farm.py)")),
                 "measured_on_hardware": ("this line" if world > 1 else "1 GPU"),
-                "cu_partition": ({"communication_stream_cus": comm_cus, "compute_stream_cus": torch.cuda.get_device_properties(dev).multi_processor_count - comm_cus} if comm_cus else None),
+                "cu_partition": ({"communication_stream_cus": comm_cus, "compute_stream_cus": device_cus - comm_cus} if comm_cus else None),
                 "payload": args.payload if gathering else None,
                 "payload_bytes_per_rank": pbytes if gathering else None,
                 "parallelism": f"tile-farm x{world}",
