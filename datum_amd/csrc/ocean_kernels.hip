@@ -294,17 +294,9 @@ namespace ocean
     return fmodf(phase + wdt, 6.2831855f);
   }
 
-  // the same for 0 <= phase < 2 pi and 0 <= w*dt < 2 pi, which is what the fused row pass is given (the host
-  // checks both and otherwise runs the phase-only kernel first): then 0 <= a < 4 pi and fmod(a, 2 pi) is a or
-  // a - 2 pi, the subtraction being exact (Sterbenz), so the result is bit-identical to fmod's
-  __device__ __forceinline__ float advance_phase_fast(float phase, float wdt)
-  {
-    const float twopi = 6.2831855f;
-
-    float a = phase + wdt;
-
-    return (a >= twopi) ? a - twopi : a;
-  }
+  // (the fused row pass is given 0 <= phase < 2 pi and 0 <= w*dt < 2 pi -- the host checks both and otherwise runs the phase-only
+  // kernel first: then 0 <= a < 4 pi and fmod(a, 2 pi) is a or a - 2 pi, the subtraction being exact (Sterbenz), bit-identical to fmod's:
+  // the row pass's packed select)
 
   //|---------------------- ocean.sim -----------------------------------------
 
@@ -353,14 +345,6 @@ namespace ocean
     cf const m = cmul(cf{ h0mk.x, h0mk.y }, e);
 
     return add_conj(u, m);
-  }
-
-  // 1 / |k| with the bare hardware reciprocal square root (1 ulp; k2 is never denormal on these grids), 0 at k = 0
-  __device__ __forceinline__ float kinv_fast(float kx, float ky)
-  {
-    float k2 = kx * kx + ky * ky;
-
-    return (k2 != 0.0f) ? __builtin_amdgcn_rsqf(k2) : 0.0f;
   }
 
   // k of sim.comp:52 and its normalisation (sim.comp:54)
@@ -709,9 +693,6 @@ namespace ocean
     // (profiles/r05_rowpass_forms.txt).  Not below: 512^2 is latency-bound and the form doubles the barrier phases.
     static constexpr bool SEQ = N >= 1024;
     static constexpr int K = SEQ ? 1 : 2;                                  // LDS lines per row
-    // the prologue two slots per instruction -- not from 2048^2 up, where the sequential form's registers are full (4096^2 fp16: 56
-    // bytes of spill and 134 us packed against 28 bytes and 124-128 us: profiles/r04_rowpass_packed.txt)
-    static constexpr bool PACKED = N <= 1024;
     static constexpr int LINE = LineFFT<N, 1, E>::LINE;                    // >= N + 2: element 0 once more at index N (the Hermitian swap)
     static constexpr int GROUPS = (N / 2) / PAIRS;                      // workgroups per cascade
     static constexpr size_t LDS = ((size_t)LineFFT<N, 1, E>::MIDTAB + (size_t)PAIRS * 2 * K * LINE) * sizeof(cf);
@@ -908,9 +889,7 @@ namespace ocean
         {
           float const dt = a.dt[k];
 
-          if constexpr (C::PACKED)
-          {
-          // two slots per instruction: w = omega dt, a = phase + w, b = a - 2 pi (same roundings as advance_phase_fast), then the select
+          // two slots per instruction: w = omega dt, a = phase + w, b = a - 2 pi (the roundings of phase + w dt, see advance_phase), then the select
           f2_ const dt2 = { dt, dt };
 
           #pragma unroll
@@ -922,13 +901,6 @@ namespace ocean
 
             ph[s] = (sum.x >= 6.2831855f) ? wrapped.x : sum.x;
             ph[s + 1] = (sum.y >= 6.2831855f) ? wrapped.y : sum.y;
-          }
-          }
-          else
-          {
-          #pragma unroll
-          for(int s = 0; s < E; ++s)
-            ph[s] = advance_phase_fast(ph[s], in.om[s] * dt);
           }
         }
 
@@ -942,8 +914,7 @@ namespace ocean
       // ocean.sim once per point; the value goes to the thread that holds the negated index
       cf h[E];
 
-      if constexpr (C::PACKED)
-      {
+      // (two slots per instruction throughout the prologue: since round 5's register savings at every size -- 2048^2 x 4 row pass 110 -> 106-107 us)
       #pragma unroll
       for(int s = 0; s < E; s += 2)
       {
@@ -960,22 +931,6 @@ namespace ocean
 
           swap_out[t + T * (s + i)] = h[s + i];
         }
-      }
-      }
-      else
-      {
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-      {
-        float sn, cs;
-        sincos_row<WILD>(ph[s], &sn, &cs);
-
-        cf const e = cf{ cs, sn };
-
-        h[s] = add_conj(cmul(cf{ hk[s].x, hk[s].y }, e), cmul(cf{ hm[s].x, hm[s].y }, e));      // sim_height_products
-
-        swap_out[t + T * s] = h[s];
-      }
       }
 
       // element 0 once more at index N: the partner of x is N - x for every x, without a wrap
@@ -994,8 +949,6 @@ namespace ocean
 
       cf v[2][E];
 
-      if constexpr (C::PACKED)
-      {
       // k of sim.comp:52 for two slots at a time: (float)x - N/2 is an exact integer, so xf0 + T s equals it bit for bit, and the
       // products keep wavevector()'s order; 1 / |k| by the bare reciprocal square root of max(k^2, smallest normal) -- at the one
       // point with k = 0 both components of k are 0 and k^ comes out 0 as sim.comp:54's guard has it
@@ -1033,33 +986,6 @@ namespace ocean
             v[1][s + i] = fma_negi_h<1>(scale_real_h<1>(hh, s2), hhy, khy);
           }
         }
-      }
-      }
-      else
-      {
-      #pragma unroll
-      for(int s = 0; s < E; ++s)
-      {
-        int const x = t + T * s;
-
-        // h~ at the negated index N - x (no wrap: element 0 also sits at index N), slot to slot a constant apart
-        cf const n = swap_in[(N - t) - s * T];
-
-        float const kx = wavevector(x, N, cc.scale);
-        float const kinv = kinv_fast(kx, ky);
-        float const khx = kx * kinv, khy = ky * kinv;
-
-        // TWICE the Hermitian parts (the column pass folds the 1/2 into its sign factor): of h~, and of h~ as it enters hx, hy
-        cf const hh = add_conj(h[s], n);                                // h~[k] + conj(h~[-k])
-        cf const hhx = (s == 0) ? fma_conj(hh, n, cx) : hh;
-        cf const hhy = fma_conj(hh, n, cy);
-
-        float const s2 = 2.0f * slot_sine<E>(ca, s);                    // 2 sin(2 pi x / N)
-
-        // C = h_H + i (-i k^x hhx) = h_H + k^x hhx ;  D = -i k^y hhy + 2 sin(theta) h_H
-        v[0][s] = fma_real(hh, hhx, khx);
-        v[1][s] = fma_negi(scale_real(hh, s2), hhy, khy);
-      }
       }
 
       // every thread has fetched its partner values before pass 0 overwrites the lines
