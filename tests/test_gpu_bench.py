@@ -72,3 +72,6 @@ def test_one_rank_group_with_the_native_gather():
     assert "datum_ocean_farm_" in j["config"]["collective_backend"] and j["config"]["payload_bytes_per_rank"] == 512 * 512 * 2 * 12
     assert j["gather_ms"] > 0 and j["value"] > 0
     assert j["without_gather"]["value"] > 0 and j["without_gather"]["ms_per_step"] > 0
+    # the farm's two streams on disjoint compute units by default (datum_ocean_farm_partition: an eighth of the device for the collective)
+    part = j["config"]["cu_partition"]
+    assert part and part["communication_stream_cus"] == 32 and part["communication_stream_cus"] + part["compute_stream_cus"] == 256
