@@ -772,6 +772,9 @@ def main():
 
     oc.bind_maps(0, 0)
     oc.set_stream(None)
+    # (with the CU partition torch's current stream is the module's own stream, which dies with the handle)
+    torch.cuda.synchronize(dev)
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))
     oc.close()
 
     if multi:
