@@ -2,7 +2,6 @@
 (examples/ocean/ocean.cpp): through the compiled example program and through the flat C view used by Python."""
 
 import os
-import re
 import subprocess
 
 import numpy as np

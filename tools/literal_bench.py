@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-import torch
+import torch  # noqa: F401  (loads the HIP runtime the module links against)
 
 from datum_amd import capi, host_api
 
