@@ -759,7 +759,8 @@ def main():
             "value_compute_only": grids / (compute_ms * 1e-3) if (compute_ms > 0 and args.gather != "serial") else None,
             "without_gather": ({"value": grids / plain_elapsed, "unit": "grids/s", "ms_per_step": plain_elapsed * 1e3 / args.steps,
                                 "what": f"the same {args.steps} steps once more after the timed region with no pack and no collective in flight, timed the same way "
-                                        "(barriers, max over ranks): the tiles' own throughput (SURVEY.md 8e (i)); `value` is the figure WITH the gather (8e (ii))"}
+                                        "(barriers, max over ranks): the tiles' own throughput (SURVEY.md 8e (i)); `value` is the figure WITH the gather (8e (ii))"
+                                        + (f"; still on the {device_cus - comm_cus} compute units the partition leaves the step (config.cu_partition)" if comm_cus else "")}
                                if plain_elapsed > 0 else None),
         }
 
