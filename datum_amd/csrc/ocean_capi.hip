@@ -381,10 +381,21 @@ namespace
     {
       int const blocks = std::min<size_t>((size_t)ctx->cus * 8, ((size_t)ctx->cascades * plane(ctx) / 4 + 255) / 256);
 
+      auto log2of = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+
+      int const N = ctx->N, B = band_cols(N), PW = map_patch_cols(N), PH = map_patch_rows(N);
+
+      PackShape sh;
+      sh.n2 = log2of(N);
+      sh.pw2 = log2of(PW);
+      sh.bp2 = log2of(B / PW);
+      sh.bandpatches2 = log2of((N / PH) * (B / PW));
+      sh.b2 = log2of(B);
+
       if (format == DATUM_OCEAN_PAYLOAD_XYZ16)
-        hipLaunchKernelGGL(ocean_pack_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device);
+        hipLaunchKernelGGL(ocean_pack_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device, sh);
       else
-        hipLaunchKernelGGL(ocean_pack_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device);
+        hipLaunchKernelGGL(ocean_pack_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device, sh);
 
       HIPCHECK(ctx, hipGetLastError());
     }

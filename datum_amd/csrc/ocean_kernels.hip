@@ -147,12 +147,6 @@ namespace ocean
   // bytes from a texel's patch to the patch of the same column k * PH rows on
   __host__ __device__ __forceinline__ constexpr int map_compact_patchrow_bytes(int N) { return (band_cols(N) / map_patch_cols(N)) * MAP_PATCH_BYTES; }
 
-  // (dx, dy, dz, nx) of a texel (pack kernel)
-  __host__ __device__ __forceinline__ float4 map_displacement(float4 const *maps, int N, int y, int x)
-  {
-    return *reinterpret_cast<float4 const*>(reinterpret_cast<char const*>(maps) + map_compact_a(N, y, x));
-  }
-
   //|---------------------- buffer addressing ----------------------------------
   // Global accesses whose addresses differ between a thread's slots only by a wave-uniform amount go through
   // buffer instructions: one 32-bit VGPR offset per thread plus an SGPR offset per access, instead of a 64-bit
@@ -1418,48 +1412,72 @@ namespace ocean
   //|---------------------- all-gather payload ---------------------------------
   // What a rank sends to its peers when the tiles of a farm are reassembled: the displacement layer
   // (dx, dy, dz) of every cascade, row-major [cascade][y][x], as three floats (12 B per point) or four halves
-  // (dx, dy, dz, 0: 8 B per point).  One thread per group of four texels: a 64-byte run in, 48 or 32 bytes out.
+  // (dx, dy, dz, 0: 8 B per point).  One thread per texel IN THE ORDER OF THE MAP LAYOUT: consecutive lanes read consecutive 16-byte
+  // parts A (patch after patch, the 128-byte parts B skipped: whole lines, every byte of them used by the wave that fetched them) and
+  // write 12 or 8 bytes each into runs of PW x (lanes / 16) texels per row.  Round 5: 39.7 -> 18.5 us for xyz32 at 1024^2 x 4 (6.35 TB/s), 169 -> 97 us at x 16
+  // (up to round 4 a thread read the four texels of a patch row -- every line fetched by two far-apart waves -- and wrote 48 bytes
+  // at a 48-byte stride: tools/dbg/pack_time.py).
+  struct PackShape
+  {
+    int n2;                 // log2 N
+    int pw2;                // log2 of a patch's width
+    int bp2;                // log2 of the patches in a row of patches of one band (B / PW)
+    int bandpatches2;       // log2 of the patches per band ((N / PH) * (B / PW))
+    int b2;                 // log2 of the band's columns
+  };
 
   template<bool HALF>
-  __global__ void __launch_bounds__(256) ocean_pack_kernel(float4 const *maps, int N, int cascades, void *payload)
+  __global__ void __launch_bounds__(256) ocean_pack_kernel(float4 const *maps, int N, int cascades, void *payload, PackShape sh)
   {
+    size_t const plane = (size_t)N * N;
+    size_t const total = (size_t)cascades * plane;
+    size_t const stride = (size_t)gridDim.x * blockDim.x;
 
-    size_t const groups = (size_t)cascades * N * (N / 4);
+    constexpr int U = 4;                           // texels in flight per thread
 
-    for(size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x)
+    for(size_t q0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < total; q0 += U * stride)
     {
-      size_t const row = g / (N / 4);                 // cascade * N + y
-      int const x0 = (int)(g % (N / 4)) * 4;
-
-      float4 const *src = reinterpret_cast<float4 const*>(reinterpret_cast<char const*>(maps) + (row / N) * map_cascade_bytes(N));      // the cascade's map block
-      int const y = (int)(row % N);
-
-      float4 t[4];
+      float4 v[U];
 
       #pragma unroll
-      for(int k = 0; k < 4; ++k)
-        t[k] = map_displacement(src, N, y, x0 + k);
-
-      if constexpr (HALF)
+      for(int k = 0; k < U; ++k)
       {
-        half4_ h[4];
+        size_t const q = q0 + k * stride;
 
-        #pragma unroll
-        for(int k = 0; k < 4; ++k)
-          h[k] = half4_{ (_Float16)t[k].x, (_Float16)t[k].y, (_Float16)t[k].z, (_Float16)0.0f };
+        if (q < total)
+        {
+          size_t const c = q >> (2 * sh.n2), r = q & (plane - 1);
 
-        float4 *dst = static_cast<float4*>(payload) + g * 2;
-
-        dst[0] = __builtin_bit_cast(float4, (half4_ const (&)[2])h[0]);
-        dst[1] = __builtin_bit_cast(float4, (half4_ const (&)[2])h[2]);
+          v[k] = *reinterpret_cast<float4 const*>(reinterpret_cast<char const*>(maps) + c * map_cascade_bytes(N) + (r >> 4) * MAP_PATCH_BYTES + (r & 15) * 16);
+        }
       }
-      else
-      {
-        float4 *dst = static_cast<float4*>(payload) + g * 3;
 
-        dst[0] = make_float4(t[0].x, t[0].y, t[0].z, t[1].x);
-        dst[1] = make_float4(t[1].y, t[1].z, t[2].x, t[2].y);
-        dst[2] = make_float4(t[2].z, t[3].x, t[3].y, t[3].z);
+      #pragma unroll
+      for(int k = 0; k < U; ++k)
+      {
+        size_t const q = q0 + k * stride;
+
+        if (q < total)
+        {
+          size_t const c = q >> (2 * sh.n2), r = q & (plane - 1);
+
+          // the texel of part A number j of patch P (map_compact_patch / map_compact_j read backwards)
+          int const P = (int)(r >> 4), j = (int)(r & 15);
+          int const band = P >> sh.bandpatches2, pp = P & ((1 << sh.bandpatches2) - 1);
+          int const y = ((pp >> sh.bp2) << (4 - sh.pw2)) + (j >> sh.pw2);
+          int const x = (band << sh.b2) + ((pp & ((1 << sh.bp2) - 1)) << sh.pw2) + (j & ((1 << sh.pw2) - 1));
+
+          size_t const at = c * plane + ((size_t)y << sh.n2) + x;
+
+          if constexpr (HALF)
+            static_cast<half4_*>(payload)[at] = half4_{ (_Float16)v[k].x, (_Float16)v[k].y, (_Float16)v[k].z, (_Float16)0.0f };
+          else
+          {
+            struct xyz { float x, y, z; };
+
+            static_cast<xyz*>(payload)[at] = xyz{ v[k].x, v[k].y, v[k].z };
+          }
+        }
       }
     }
   }
