@@ -369,6 +369,23 @@ namespace
     return DATUM_OCEAN_OK;
   }
 
+  // the map layout's shape as shifts (ocean_pack_kernel, ocean_export_kernel: texel <- part number)
+  PackShape pack_shape(int N)
+  {
+    auto log2of = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+
+    int const B = band_cols(N), PW = map_patch_cols(N), PH = map_patch_rows(N);
+
+    PackShape sh;
+    sh.n2 = log2of(N);
+    sh.pw2 = log2of(PW);
+    sh.bp2 = log2of(B / PW);
+    sh.bandpatches2 = log2of((N / PH) * (B / PW));
+    sh.b2 = log2of(B);
+
+    return sh;
+  }
+
   // the pack of datum_ocean_pack_displacement / datum_ocean_farm_gather, on the handle's stream (arguments checked by the callers)
   int pack_into(datum_ocean_ctx *ctx, int format, void *payload_device, size_t need)
   {
@@ -381,16 +398,7 @@ namespace
     {
       int const blocks = std::min<size_t>((size_t)ctx->cus * 8, ((size_t)ctx->cascades * plane(ctx) / 4 + 255) / 256);
 
-      auto log2of = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
-
-      int const N = ctx->N, B = band_cols(N), PW = map_patch_cols(N), PH = map_patch_rows(N);
-
-      PackShape sh;
-      sh.n2 = log2of(N);
-      sh.pw2 = log2of(PW);
-      sh.bp2 = log2of(B / PW);
-      sh.bandpatches2 = log2of((N / PH) * (B / PW));
-      sh.b2 = log2of(B);
+      PackShape const sh = pack_shape(ctx->N);
 
       if (format == DATUM_OCEAN_PAYLOAD_XYZ16)
         hipLaunchKernelGGL(ocean_pack_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->maps, ctx->N, ctx->cascades, payload_device, sh);
@@ -1512,17 +1520,43 @@ int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps)
   return DATUM_OCEAN_OK;
 }
 
-// a cascade's maps as the reference's 2-layer RGBA32F image (datum_ocean_export_maps); one thread per texel
-__global__ void __launch_bounds__(256) ocean_export_kernel(char const *maps, int N, float4 *dst)
+// a cascade's maps as the reference's 2-layer RGBA32F image (datum_ocean_export_maps); one thread per texel.  LAYOUT (up to 1024^2): in the
+// order of the map layout like the pack kernel -- consecutive lanes read consecutive parts A and B of a patch, 16-byte stores in runs of
+// a patch row (1024^2: 13.0 -> 9.3 us); otherwise in the order of the image -- from 2048^2 up, beyond the Infinity Cache, whole lines
+// written count for more than whole lines read (2048^2: 35.4 against 38.0 us, 4096^2: 228 against 240 us; profiles/r05_pack.txt)
+template<bool LAYOUT>
+__global__ void __launch_bounds__(256) ocean_export_kernel(char const *maps, int N, float4 *dst, ocean::PackShape sh)
 {
   size_t const P = (size_t)N * N;
 
-  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (size_t)gridDim.x * blockDim.x)
+  for(size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < P; r += (size_t)gridDim.x * blockDim.x)
   {
-    int const y = (int)(i / N), x = (int)(i % N);
+    size_t i, oa, ob;
 
-    float4 const a = *reinterpret_cast<float4 const*>(maps + map_compact_a(N, y, x));
-    float2 const b = *reinterpret_cast<float2 const*>(maps + map_compact_b(N, y, x));
+    if constexpr (LAYOUT)
+    {
+      int const patch = (int)(r >> 4), j = (int)(r & 15);
+
+      oa = (size_t)patch * ocean::MAP_PATCH_BYTES + j * 16;
+      ob = (size_t)patch * ocean::MAP_PATCH_BYTES + 256 + j * 8;
+
+      int const band = patch >> sh.bandpatches2, pp = patch & ((1 << sh.bandpatches2) - 1);
+      int const y = ((pp >> sh.bp2) << (4 - sh.pw2)) + (j >> sh.pw2);
+      int const x = (band << sh.b2) + ((pp & ((1 << sh.bp2) - 1)) << sh.pw2) + (j & ((1 << sh.pw2) - 1));
+
+      i = ((size_t)y << sh.n2) + x;
+    }
+    else
+    {
+      int const y = (int)(r >> sh.n2), x = (int)(r & (N - 1));
+
+      oa = ocean::map_compact_a(N, y, x);
+      ob = ocean::map_compact_b(N, y, x);
+      i = r;
+    }
+
+    float4 const a = *reinterpret_cast<float4 const*>(maps + oa);
+    float2 const b = *reinterpret_cast<float2 const*>(maps + ob);
 
     dst[i] = make_float4(a.x, a.y, a.z, 0.0f);
     dst[P + i] = make_float4(a.w, b.x, b.y, 0.0f);
@@ -1545,8 +1579,12 @@ int datum_ocean_export_maps(datum_ocean_t ctx, int cascade, void *device_dst, si
   size_t const P = plane(ctx);
   int const blocks = (int)((P + 255) / 256 < 4096 ? (P + 255) / 256 : 4096);
 
-  hipLaunchKernelGGL(ocean_export_kernel, dim3(blocks), dim3(256), 0, ctx->stream,
-                     reinterpret_cast<char const*>(ctx->maps) + (size_t)cascade * map_cascade_bytes(ctx->N), ctx->N, static_cast<float4*>(device_dst));
+  char const *block = reinterpret_cast<char const*>(ctx->maps) + (size_t)cascade * map_cascade_bytes(ctx->N);
+
+  if (ctx->N <= 1024)
+    hipLaunchKernelGGL(ocean_export_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, block, ctx->N, static_cast<float4*>(device_dst), pack_shape(ctx->N));
+  else
+    hipLaunchKernelGGL(ocean_export_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, block, ctx->N, static_cast<float4*>(device_dst), pack_shape(ctx->N));
 
   HIPCHECK(ctx, hipGetLastError());
 
