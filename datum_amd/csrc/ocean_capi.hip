@@ -1520,6 +1520,8 @@ int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps)
   return DATUM_OCEAN_OK;
 }
 
+}   // extern "C"
+
 // a cascade's maps as the reference's 2-layer RGBA32F image (datum_ocean_export_maps); one thread per texel.  LAYOUT (up to 1024^2): in the
 // order of the map layout like the pack kernel -- consecutive lanes read consecutive parts A and B of a patch, 16-byte stores in runs of
 // a patch row (1024^2: 13.0 -> 9.3 us); otherwise in the order of the image -- from 2048^2 up, beyond the Infinity Cache, whole lines
@@ -1562,6 +1564,9 @@ __global__ void __launch_bounds__(256) ocean_export_kernel(char const *maps, int
     dst[P + i] = make_float4(a.w, b.x, b.y, 0.0f);
   }
 }
+
+extern "C"
+{
 
 int datum_ocean_export_maps(datum_ocean_t ctx, int cascade, void *device_dst, size_t bytes)
 {
