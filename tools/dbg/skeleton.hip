@@ -12,10 +12,13 @@ typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
 // row pass: 256 threads = rows p and N - p, thread t of 128 per row holds x = t + 128 s (MODE 0) or four consecutive x in each half of the row (MODE 1)
 template<int MODE>
-__global__ void __launch_bounds__(256) rowskel(float2 const* __restrict__ h0, float* __restrict__ phase, float const* __restrict__ omega, float4* __restrict__ spec, float const* __restrict__ omegawide, int delay = 0) {
+__global__ void __launch_bounds__(256) rowskel(float2 const* __restrict__ h0, float* __restrict__ phase, float const* __restrict__ omega, float4* __restrict__ spec, float const* __restrict__ omegawide, int delay = 0, int per = 1) {
   extern __shared__ unsigned char occupancy_cap[];      // (dynamic LDS of the launch: caps the workgroups per CU, nothing is stored there)
   constexpr int T = 128, E = 8;
-  int const item = blockIdx.x; int const c = item / (N / 2), q = item % (N / 2); int const p = (q & 7) * (N / 16) + (q >> 3);       // the kernel's XCD bands
+  float2 const *h0_ = h0; float *phase_ = phase; float4 *spec_ = spec; float const *omega_ = omega, *omegawide_ = omegawide;
+  for (int rep = 0; rep < per; ++rep) {
+  h0 = h0_; phase = phase_; spec = spec_; omega = omega_; omegawide = omegawide_;
+  int const item = blockIdx.x * per + rep; int const c = item / (N / 2), q = item % (N / 2); int const p = (q & 7) * (N / 16) + (q >> 3);       // the kernel's XCD bands
   int const half = threadIdx.x / T, t = threadIdx.x % T; int const y = half ? (p == 0 ? N / 2 : N - p) : p;
   size_t const plane = (size_t)N * N;
   h0 += c * plane; phase += c * plane; spec += c * plane; omega += (size_t)c * Q * Q; omegawide += (size_t)c * Q * N;
@@ -50,6 +53,7 @@ __global__ void __launch_bounds__(256) rowskel(float2 const* __restrict__ h0, fl
   for (int s = 0; s < E; ++s) { int x = t + T * s;
     u4 d = { __float_as_uint(a[s].x + b[s].x), __float_as_uint(a[s].y - b[s].y), __float_as_uint(ph[s]), __float_as_uint(om[s]) };
     __builtin_amdgcn_raw_buffer_store_b128(d, rsp, (int)blocked<N>(y, x) * 16, 0, SPEC_STORE_AUX); }
+  }
 }
 
 // column pass: a tile of four columns per 256-thread workgroup, threads column-fastest, 16 rows y = t + 64 s per thread: one 16-byte load per point from
@@ -81,6 +85,8 @@ int main() {
     for (int wgs : {8, 6, 4}) for (int delay : {0, 6, 12}) { char name[160]; snprintf(name, sizeof(name), "row pass skeleton, %d workgroups per CU, %.1f us idle between loads and spectrum stores", wgs, delay * 0.427);
       size_t lds = wgs == 8 ? 0 : (size_t)(160 * 1024 / wgs) - 512; hipFuncSetAttribute(reinterpret_cast<void const*>(&rowskel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
       timeit(name, 32.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C), dim3(256), lds, 0, h0, phase, omega, spec, omegawide, delay); }); }
+    for (int per : {1, 2, 4, 8}) { char name[160]; snprintf(name, sizeof(name), "row pass skeleton, %d pairs per workgroup one after the other (%d workgroups)", per, N / 2 * C / per);
+      timeit(name, 32.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C/per), dim3(256), 0, 0, h0, phase, omega, spec, omegawide, 0, per); }); }
     timeit("both, back to back (72 B/pt: the step)", 72.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C), dim3(256), 0, 0, h0, phase, omega, spec, omegawide); hipLaunchKernelGGL(colskel, dim3(N/4*C), dim3(256), 0, 0, spec, maps); });
   }
   return 0;
