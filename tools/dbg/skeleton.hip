@@ -12,14 +12,17 @@ typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
 // row pass: 256 threads = rows p and N - p, thread t of 128 per row holds x = t + 128 s (MODE 0) or four consecutive x in each half of the row (MODE 1)
 template<int MODE>
-__global__ void __launch_bounds__(256) rowskel(float2 const* __restrict__ h0, float* __restrict__ phase, float const* __restrict__ omega, float4* __restrict__ spec, float const* __restrict__ omegawide, int delay = 0, int per = 1) {
+__global__ void __launch_bounds__(1024) rowskel(float2 const* __restrict__ h0, float* __restrict__ phase, float const* __restrict__ omega, float4* __restrict__ spec, float const* __restrict__ omegawide, int delay = 0, int per = 1) {
   extern __shared__ unsigned char occupancy_cap[];      // (dynamic LDS of the launch: caps the workgroups per CU, nothing is stored there)
   constexpr int T = 128, E = 8;
   float2 const *h0_ = h0; float *phase_ = phase; float4 *spec_ = spec; float const *omega_ = omega, *omegawide_ = omegawide;
   for (int rep = 0; rep < per; ++rep) {
   h0 = h0_; phase = phase_; spec = spec_; omega = omega_; omegawide = omegawide_;
-  int const item = blockIdx.x * per + rep; int const c = item / (N / 2), q = item % (N / 2); int const p = (q & 7) * (N / 16) + (q >> 3);       // the kernel's XCD bands
-  int const half = threadIdx.x / T, t = threadIdx.x % T; int const y = half ? (p == 0 ? N / 2 : N - p) : p;
+  int const side = blockDim.x >= 256 ? blockDim.x / 256 : 1;     // row pairs side by side in one workgroup (256 threads each)
+  int const sub = blockDim.x >= 256 ? 1 : 256 / blockDim.x;       // or workgroups per pair (128 threads: one row each; 64: half a row)
+  int const tid = blockDim.x >= 256 ? threadIdx.x % 256 : (blockIdx.x % sub) * blockDim.x + threadIdx.x;
+  int const item = ((blockIdx.x / sub) * side + threadIdx.x / 256) * per + rep; int const c = item / (N / 2), q = item % (N / 2); int const p = (q & 7) * (N / 16) + (q >> 3);       // the kernel's XCD bands
+  int const half = tid / T, t = tid % T; int const y = half ? (p == 0 ? N / 2 : N - p) : p;
   size_t const plane = (size_t)N * N;
   h0 += c * plane; phase += c * plane; spec += c * plane; omega += (size_t)c * Q * Q; omegawide += (size_t)c * Q * N;
   __amdgpu_buffer_rsrc_t rph = make_rsrc(phase, plane * 4), rsp = make_rsrc(spec, plane * 16);
@@ -87,6 +90,10 @@ int main() {
       timeit(name, 32.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C), dim3(256), lds, 0, h0, phase, omega, spec, omegawide, delay); }); }
     for (int per : {1, 2, 4, 8}) { char name[160]; snprintf(name, sizeof(name), "row pass skeleton, %d pairs per workgroup one after the other (%d workgroups)", per, N / 2 * C / per);
       timeit(name, 32.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C/per), dim3(256), 0, 0, h0, phase, omega, spec, omegawide, 0, per); }); }
+    for (int threads : {128, 64}) { char name[160]; snprintf(name, sizeof(name), "row pass skeleton, %d workgroups of %d threads (a pair split over %d workgroups)", N / 2 * C * 256 / threads, threads, 256 / threads);
+      timeit(name, 32.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C*256/threads), dim3(threads), 0, 0, h0, phase, omega, spec, omegawide, 0, 1); }); }
+    for (int side : {1, 2, 4}) { char name[160]; snprintf(name, sizeof(name), "row pass skeleton, %d pairs SIDE BY SIDE per workgroup (%d workgroups of %d threads)", side, N / 2 * C / side, 256 * side);
+      timeit(name, 32.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C/side), dim3(256 * side), 0, 0, h0, phase, omega, spec, omegawide, 0, 1); }); }
     timeit("both, back to back (72 B/pt: the step)", 72.0*C*plane, [&]{ hipLaunchKernelGGL(rowskel<0>, dim3(N/2*C), dim3(256), 0, 0, h0, phase, omega, spec, omegawide); hipLaunchKernelGGL(colskel, dim3(N/4*C), dim3(256), 0, 0, spec, maps); });
   }
   return 0;
