@@ -71,6 +71,8 @@ def parse():
                          "the environment and the rendezvous of an N-rank run without the ocean (tests/test_bench_launcher.py)")
     ap.add_argument("--spectrum", choices=("fp32", "fp16"), default="fp32",
                     help="storage of the work spectrum between the two passes (fp16: BASELINE.json configs[4]; arithmetic stays fp32)")
+    ap.add_argument("--cascade-group", type=int, default=0,
+                    help="cascades per launch of the two passes (datum_ocean_set_cascade_group); 0 = the module's own choice (sized to the Infinity Cache)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
     ap.add_argument("--no-frame", action="store_true", help="skip the 64 x 64 reference-frame timing")
     ap.add_argument("--no-check", action="store_true", help="skip the output sanity check (timing-only ablation builds)")
@@ -379,6 +381,8 @@ def main():
     # state: this rank's cascades, seeded on the host exactly as seed_ocean does (mt19937(1000 + global index))
     oc = capi.Ocean(N, C, device=local_rank)
     oc.set_spectrum_format(args.spectrum == "fp16")
+    oc.set_cascade_group(args.cascade_group)
+    cascade_group, launches_per_pass = oc.cascade_group()
     for c, g in enumerate(farm.owned_grids(rank, world, C)):
         ws = farm.grid_wavescale(g, C)
         p = host_api.OceanParams(N, **dict(host_api.EXAMPLE_TUNABLES, wavescale=ws))
@@ -438,9 +442,15 @@ def main():
                 oc.set_stream(None)
     elif gathering:
         if comm_cus:
-            stream = farm.cu_masked_stream(dev, ((1 << device_cus) - 1) ^ ((1 << comm_cus) - 1))
-            torch.cuda.set_stream(stream)
-            oc.set_stream(stream.cuda_stream)
+            try:
+                stream = farm.cu_masked_stream(dev, ((1 << device_cus) - 1) ^ ((1 << comm_cus) - 1))
+            except Exception as e:
+                # (a runtime without CU masks: both streams on the whole device, as the native path falls back)
+                print(f"bench.py: rank {rank}: no CU-masked stream ({e}); both streams on the whole device", file=sys.stderr)
+                comm_cus = 0
+            else:
+                torch.cuda.set_stream(stream)
+                oc.set_stream(stream.cuda_stream)
         tg = farm.TileGather(farm.payload_numel(N, C, args.payload), pdtype, dev, world, standin_peers=args.standin_peers,
                              force_collective=args.force_collective, standin_workgroups=args.standin_workgroups, standin_gbps=args.standin_gbps,
                              comm_cus=comm_cus)
@@ -562,26 +572,37 @@ def main():
                 big.set_cascade(c, ws, 1.35)
                 big.upload_state(c, p.height)
                 del p
-            for _ in range(5):
-                big.update(DT)
-                big.displace()
-            r0, r1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
-            big.profile_begin(10, 1)
-            r0.record(stream)
-            for _ in range(10):
-                big.update(DT)
-                big.displace()
-            r1.record(stream)
-            torch.cuda.synchronize(dev)
-            brow_ms, bcol_ms, bn = big.profile_end()
             brow_b, bcol_b = big.algorithmic_bytes()
+
+            def regime_leg(group):
+                """ten steps after five with `group` cascades per launch of either pass (0: the module's choice)"""
+                big.set_cascade_group(group)
+                for _ in range(5):
+                    big.update(DT)
+                    big.displace()
+                r0, r1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+                big.profile_begin(10, 1)
+                r0.record(stream)
+                for _ in range(10):
+                    big.update(DT)
+                    big.displace()
+                r1.record(stream)
+                torch.cuda.synchronize(dev)
+                brow_ms, bcol_ms, bn = big.profile_end()
+                g, launches = big.cascade_group()
+                return {"cascades_per_launch": g, "launches_per_pass_and_step": launches,
+                        "step_frac": (brow_b + bcol_b) / ((brow_ms + bcol_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "col_frac": bcol_b / (bcol_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "row_frac": brow_b / (brow_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "rowpass_ms": brow_ms, "colpass_ms": bcol_ms, "steps_timed": bn,
+                        "grids_per_s": 10 * RC / (r0.elapsed_time(r1) * 1e-3),
+                        "frac_on_bytes_moved": ((48.0 + capi.map_layout(N)[3]) * N * N * RC) / ((brow_ms + bcol_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+            one_launch = regime_leg(RC)          # every cascade in one launch per pass (the form up to round 5)
+            grouped = regime_leg(0)              # the module's cascade groups (what datum_ocean_displace does by default)
             big.set_stream(None)
-        regime = {"workload": f"{N}x{N} x {RC} cascades fp32 (1 GB working set: beyond the 256 MiB Infinity Cache), 10 steps after 5, outside the timed region",
-                  "step_frac": (brow_b + bcol_b) / ((brow_ms + bcol_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  "col_frac": bcol_b / (bcol_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "row_frac": brow_b / (brow_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  "rowpass_ms": brow_ms, "colpass_ms": bcol_ms, "launches_timed": bn,
-                  "grids_per_s": 10 * RC / (r0.elapsed_time(r1) * 1e-3),
-                  "frac_on_bytes_moved": ((48.0 + capi.map_layout(N)[3]) * N * N * RC) / ((brow_ms + bcol_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        regime = dict(grouped, workload=f"{N}x{N} x {RC} cascades fp32 (1 GB working set: beyond the 256 MiB Infinity Cache), 10 steps after 5, outside the timed region; "
+                                        "rowpass_ms / colpass_ms are sums over a step's launches",
+                      one_launch_per_pass=one_launch)
 
     # ocean.gen (SURVEY.md 8d: reported separately, as vertices/s): the 1024 x 1024 projected-grid mesh of the example
     # (examples/ocean/ocean.cpp:59) from cascade 0's maps, outside the timed region above
@@ -695,6 +716,8 @@ def main():
                 "baseline_config": baseline_config(N, C, world, args.spectrum),
                 "resolution": N,
                 "cascades_per_gpu": C,
+                "cascades_per_launch": cascade_group,
+                "launches_per_pass_and_step": launches_per_pass,
                 "grids_per_step": C * world,
                 "gather": ((f"{args.gather}: one all-gather of the {args.payload} payload every {every} step(s), {gathers} inside the timed region"
                             + (", each on a second stream under the following steps' kernels" if args.gather == "pipelined" else "")) if every > 0 else
@@ -742,9 +765,10 @@ def main():
                 "frac_of_peak_on_bytes_moved": {"rowpass": moved[0] / (row_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if row_ms > 0 else None,
                                                 "colpass": moved[1] / (col_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if col_ms > 0 else None,
                                                 "step": (moved[0] + moved[1]) / ((row_ms + col_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS if row_ms + col_ms > 0 else None},
-                "bytes_per_launch": phys_bytes,
-                "survey_bytes_per_launch": dom[2],
-                "ms_per_launch": dom[1],
+                # (a step launches either kernel once per cascade group: config.launches_per_pass_and_step; rowpass.ms / colpass.ms below are per STEP)
+                "bytes_per_launch": phys_bytes / launches_per_pass,
+                "survey_bytes_per_launch": dom[2] / launches_per_pass,
+                "ms_per_launch": dom[1] / launches_per_pass,
                 "rowpass": {"ms": row_ms, "bytes": row_b, "GBps": row_b / (row_ms * 1e-3) / 1e9 if row_ms > 0 else 0.0},
                 "colpass": {"ms": col_ms, "bytes": col_b, "GBps": col_b / (col_ms * 1e-3) / 1e9 if col_ms > 0 else 0.0},
                 "step_GBps": step_ach,
@@ -771,11 +795,14 @@ def main():
 
         os.write(line_fd, (json.dumps(line) + "\n").encode())
 
+    if tg is not None:
+        tg.close()
     oc.bind_maps(0, 0)
     oc.set_stream(None)
     # (with the CU partition torch's current stream is the module's own stream, which dies with the handle)
     torch.cuda.synchronize(dev)
     torch.cuda.set_stream(torch.cuda.default_stream(dev))
+    farm.release_cu_masked_stream(stream)        # (a no-op for any other stream)
     oc.close()
 
     if multi:

@@ -108,11 +108,19 @@ SYMBOLS = {
     "datum_ocean_abi_version": (I, []),
     "datum_ocean_set_literal_transform": (I, [P, I]),
     "datum_ocean_export_maps": (I, [P, I, P, ctypes.c_size_t]),
+    "datum_ocean_farm_stream_flags": (I, [P, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
+    "datum_ocean_set_cascade_group": (I, [P, I]),
+    "datum_ocean_cascade_group": (I, [P, ctypes.POINTER(I), ctypes.POINTER(I)]),
 }
 
 
+# DATUM_OCEAN_ABI_VERSION of include/datum_ocean_hip.h as SYMBOLS above was written against it.  A constant, not a read of the header: an
+# installed or copied package has no include/ beside it (tests/test_golden_and_abi.py asserts that the two agree in the source tree).
+ABI_VERSION = 7
+
+
 def header_abi_version():
-    """DATUM_OCEAN_ABI_VERSION of include/datum_ocean_hip.h, the contract this binding was written against."""
+    """DATUM_OCEAN_ABI_VERSION as include/datum_ocean_hip.h states it (source tree only: the tests compare it with ABI_VERSION)."""
     import re
 
     text = open(os.path.join(os.path.dirname(_HERE), "include", "datum_ocean_hip.h")).read()
@@ -147,9 +155,9 @@ def load():
             have = lib.datum_ocean_abi_version()
         except AttributeError:
             have = None
-        want = header_abi_version()
+        want = ABI_VERSION
         if have != want:
-            raise OSError(f"{LIBPATH} reports ABI version {have}, include/datum_ocean_hip.h is version {want}: rebuild the HIP module (`make`)")
+            raise OSError(f"{LIBPATH} reports ABI version {have}, this binding is written against version {want} of include/datum_ocean_hip.h: rebuild the HIP module (`make`)")
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype = res
@@ -404,6 +412,22 @@ class Ocean:
     def set_literal_transform(self, on):
         """validation mode: displace through the reference's radix-2 transforms and literal twiddle table (datum_ocean_set_literal_transform)"""
         self._check(self.lib.datum_ocean_set_literal_transform(self.h, 1 if on else 0))
+
+    def farm_stream_flags(self):
+        """hipStreamGetFlags of (communication stream, own stream): 0 = hipStreamDefault (synchronises with the null stream), 1 = hipStreamNonBlocking"""
+        a, b = ctypes.c_uint(), ctypes.c_uint()
+        self._check(self.lib.datum_ocean_farm_stream_flags(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def set_cascade_group(self, cascades_per_launch):
+        """cascades per launch of the two passes; 0 = sized to the Infinity Cache (datum_ocean_set_cascade_group)"""
+        self._check(self.lib.datum_ocean_set_cascade_group(self.h, cascades_per_launch))
+
+    def cascade_group(self):
+        """(cascades per launch, launches per pass and displace call)"""
+        g, n = I(), I()
+        self._check(self.lib.datum_ocean_cascade_group(self.h, ctypes.byref(g), ctypes.byref(n)))
+        return g.value, n.value
 
     def export_maps(self, cascade, device_ptr, nbytes):
         """the cascade's maps as the reference's [layer][y][x][4] RGBA32F image, into DEVICE memory (datum_ocean_export_maps)"""

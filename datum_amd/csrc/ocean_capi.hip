@@ -37,6 +37,7 @@ struct datum_ocean_ctx
   float *phase = nullptr;
   void *spec = nullptr;               // cd[cascades][P], or ch[...] with the fp16 spectrum
   bool half = false;                  // DATUM_OCEAN_SPECTRUM_FP16
+  int cascadegroup = 0;               // cascades per launch of the two passes, 0 = sized to the Infinity Cache (cascade_group)
 
   // validation mode (datum_ocean_set_literal_transform): the reference's own radix-2 transforms with its literal twiddle table
   bool literal = false;
@@ -118,11 +119,34 @@ namespace
     a.omega = ctx->omega;
     a.ndt = ndt;
     a.cascades = ctx->cascades;
+    a.first = 0;
 
     for(int i = 0; i < MAX_PENDING; ++i)
       a.dt[i] = (i < ndt) ? dt[i] : 0.0f;
     memcpy(a.casc, ctx->casc, sizeof(a.casc));
     return a;
+  }
+
+  // Cascades per launch of the two passes.  Between the passes 16 bytes per point (8: fp16 spectrum) are written and read back once; with every
+  // cascade of the handle in one launch per pass that exchange goes out to HBM and comes back as soon as the handle's working set --
+  // h0 8 + phase 4 + work spectrum 16 + maps 24 bytes per point -- is beyond the 256 MiB Infinity Cache (from x 8 at 1024^2, from x 2 at
+  // 2048^2).  Launched group by group -- row(g), column(g), row(g + 1), ... on the same stream -- a group's spectrum is still in the cache
+  // when its column pass reads it.  The group is the largest whose own working set fits with room to spare (4 cascades at 1024^2, 1 from
+  // 2048^2 up); measured in profiles/r06_cascade_groups.txt.  Replaces the one dispatch per shader of ocean.cpp:769-789.
+  constexpr double CASCADE_GROUP_BYTES = 224.0e6;
+
+  int cascade_group(datum_ocean_ctx const *ctx)
+  {
+    int g = ctx->cascadegroup;
+
+    if (g <= 0)
+    {
+      double const per = (double)plane(ctx) * (12.0 + (ctx->half ? 8.0 : 16.0) + 24.0);
+
+      g = (int)(CASCADE_GROUP_BYTES / per);
+    }
+
+    return g < 1 ? 1 : (g > ctx->cascades ? ctx->cascades : g);
   }
 
   template<int N, bool H16>
@@ -188,8 +212,8 @@ namespace
     void *args[] = { &a };
     void const *kernel = wild ? reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16, true>) : reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>);
 
-    // work items = groups of row pairs x cascades: one workgroup each
-    int const items = C::GROUPS * ctx->cascades;
+    // work items = groups of row pairs x the cascades of this launch: one workgroup each
+    int const items = C::GROUPS * a.cascades;
 
     return launch(kernel, dim3(items), dim3(C::THREADS), args, C::LDS, ctx->stream, ev);
   }
@@ -214,7 +238,7 @@ namespace
 
     // work items = tiles x cascades; the large grids' workgroups are persistent, one per compute unit (the LDS of a
     // 1024-thread tile fills a CU), and walk their share of the items
-    int const items = ColCfg<N>::TILES * ctx->cascades;
+    int const items = ColCfg<N>::TILES * a.cascades;
     bool const walks = ctx->half ? col_walks<N, true>() : col_walks<N, false>();
     int const groups = walks ? std::min(items, ctx->cus) : items;
 
@@ -422,6 +446,10 @@ namespace
 
     (ctx ? ctx->error : g_error) = buf;
 
+    // a communicator that failed is not destroyed (ncclCommDestroy waits for its outstanding operations) but aborted: farm_teardown
+    if (ctx && ctx->farm && comm && comm == ctx->farm->comm)
+      ctx->farm->failed = true;
+
     return DATUM_OCEAN_ECOMM;
   }
 
@@ -434,11 +462,19 @@ namespace
     if (!f)
       return;
 
-    if (f->stream)
+    if (f->stream && !f->failed)
       (void)hipStreamSynchronize(f->stream);
 
     if (f->comm && f->api)
-      (void)f->api->CommDestroy(f->comm);
+    {
+      if (f->failed && f->api->CommAbort)
+        (void)f->api->CommAbort(f->comm);
+      else
+        (void)f->api->CommDestroy(f->comm);
+    }
+
+    if (f->stream && f->failed)
+      (void)hipStreamSynchronize(f->stream);
 
     for(auto &sl : f->slots)
     {
@@ -723,6 +759,9 @@ int datum_ocean_set_spectrum_format(datum_ocean_t ctx, int format)
 
   if (format != DATUM_OCEAN_SPECTRUM_FP32 && format != DATUM_OCEAN_SPECTRUM_FP16)
     return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_set_spectrum_format: unknown format");
+
+  if (format == DATUM_OCEAN_SPECTRUM_FP16 && ctx->literal)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_set_spectrum_format: the handle is in the literal mode (the reference's fp32 arithmetic); switch it off first");
 
   ctx->half = (format == DATUM_OCEAN_SPECTRUM_FP16);
 
@@ -1021,15 +1060,29 @@ int datum_ocean_displace(datum_ocean_t ctx)
   ctx->pending.clear();
 
   bool const prof = ctx->profiling && ctx->profsteps < ctx->profmax && (ctx->profcalls++ % ctx->profstride) == 0;
-  hipEvent_t *ev = prof ? &ctx->events[4 * ctx->profsteps] : nullptr;   // row start, row stop, column start, column stop
 
-  hipError_t le = hipSuccess;
+  // the two passes group by group (cascade_group): row(g), column(g), row(g + 1), ...
+  int const group = cascade_group(ctx);
+  int const groups = (ctx->cascades + group - 1) / group;
 
-  DISPATCH_N(ctx->N, le = launch_rowpass<NN>(ctx, a, ev));
-  HIPCHECK(ctx, le);
+  if (prof && ctx->events.size() < (size_t)4 * ctx->profmax * groups)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_displace: the cascade group changed while profiling");
 
-  DISPATCH_N(ctx->N, le = launch_colpass<NN>(ctx, a, ev ? ev + 2 : nullptr));
-  HIPCHECK(ctx, le);
+  for(int g = 0; g < groups; ++g)
+  {
+    a.first = g * group;
+    a.cascades = std::min(group, ctx->cascades - a.first);
+
+    hipEvent_t *ev = prof ? &ctx->events[4 * ((size_t)ctx->profsteps * groups + g)] : nullptr;   // row start, row stop, column start, column stop
+
+    hipError_t le = hipSuccess;
+
+    DISPATCH_N(ctx->N, le = launch_rowpass<NN>(ctx, a, ev));
+    HIPCHECK(ctx, le);
+
+    DISPATCH_N(ctx->N, le = launch_colpass<NN>(ctx, a, ev ? ev + 2 : nullptr));
+    HIPCHECK(ctx, le);
+  }
 
   if (prof)
     ctx->profsteps += 1;
@@ -1433,8 +1486,13 @@ int datum_ocean_farm_partition(datum_ocean_t ctx, int comm_cus)
   if (!f)
     return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_farm_partition: the handle does not farm (datum_ocean_farm_init first)");
 
+  // DATUM_OCEAN_FARM_PARTITION_AUTO: an eighth of the device in whole shares of 8 (one compute unit per XCD and share: 32 of an MI355X's
+  // 256; none on a device with fewer than 64 compute units, where the call then leaves both streams on the whole device)
+  if (comm_cus == DATUM_OCEAN_FARM_PARTITION_AUTO)
+    comm_cus = (ctx->cus / 64) * 8;
+
   if (comm_cus < 0 || comm_cus % 8 != 0 || comm_cus > ctx->cus / 2)
-    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_farm_partition: comm_cus must be 0 or a multiple of 8 (one share per XCD), at most half the device");
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_farm_partition: comm_cus must be 0, DATUM_OCEAN_FARM_PARTITION_AUTO or a multiple of 8 (one share per XCD), at most half the device");
 
   HIPCHECK(ctx, hipSetDevice(ctx->device));
 
@@ -1466,6 +1524,27 @@ int datum_ocean_farm_partition(datum_ocean_t ctx, int comm_cus)
 
   if (onown)
     ctx->stream = own;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_farm_stream_flags(datum_ocean_t ctx, unsigned int *communication_stream_flags, unsigned int *own_stream_flags)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_farm_stream_flags: null handle");
+
+  if (!ctx->farm)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_farm_stream_flags: the handle does not farm (datum_ocean_farm_init first)");
+
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+
+  // (CU-masked streams come without a flags argument: what the runtime made of them is what decides whether a null-stream operation of the
+  // caller's serialises the two streams -- include/datum_ocean_hip.h, datum_ocean_farm_partition)
+  if (communication_stream_flags)
+    HIPCHECK(ctx, hipStreamGetFlags(ctx->farm->stream, communication_stream_flags));
+
+  if (own_stream_flags)
+    HIPCHECK(ctx, hipStreamGetFlags(ctx->ownstream, own_stream_flags));
 
   return DATUM_OCEAN_OK;
 }
@@ -1603,6 +1682,13 @@ int datum_ocean_set_literal_transform(datum_ocean_t ctx, int on)
 
   HIPCHECK(ctx, hipSetDevice(ctx->device));
 
+  // (profiling samples and the fp16 spectrum format belong to the fused kernels: refused together with the literal mode rather than ignored)
+  if (on && ctx->profiling)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_set_literal_transform: a profile is open (datum_ocean_profile_end first): the literal mode's dispatches are not sampled");
+
+  if (on && ctx->half)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_set_literal_transform: the handle stores an fp16 spectrum (datum_ocean_set_spectrum_format): the literal mode is the reference's fp32 arithmetic");
+
   if (on && !ctx->litfields)
   {
     size_t const P = plane(ctx);
@@ -1618,13 +1704,63 @@ int datum_ocean_set_literal_transform(datum_ocean_t ctx, int on)
     if (rc != DATUM_OCEAN_OK)
       return rc;
 
-    HIPCHECK(ctx, hipMalloc(&ctx->litweights, weights.size() * sizeof(float)));
-    HIPCHECK(ctx, hipMemcpyAsync(ctx->litweights, weights.data(), weights.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));       // (the host vector goes out of scope)
-    HIPCHECK(ctx, hipMalloc(&ctx->litfields, 3 * P * sizeof(float2)));
+    // both buffers or neither: a failure between the two must not leave one behind for the next call to allocate over
+    float *lw = nullptr;
+    float2 *lf = nullptr;
+
+    hipError_t e = hipMalloc(&lw, weights.size() * sizeof(float));
+
+    if (e == hipSuccess)
+      e = hipMalloc(&lf, 3 * P * sizeof(float2));
+
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(lw, weights.data(), weights.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(ctx->stream);       // (the host vector goes out of scope)
+
+    if (e != hipSuccess)
+    {
+      (void)hipFree(lw);
+      (void)hipFree(lf);
+
+      return fail(ctx, (int)e, "datum_ocean_set_literal_transform: buffers of the literal mode");
+    }
+
+    ctx->litweights = lw;
+    ctx->litfields = lf;
   }
 
   ctx->literal = on != 0;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_set_cascade_group(datum_ocean_t ctx, int cascades_per_launch)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_set_cascade_group: null handle");
+
+  if (cascades_per_launch < 0)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_set_cascade_group: negative group");
+
+  if (ctx->profiling)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_set_cascade_group: a profile is open (its samples are per group)");
+
+  ctx->cascadegroup = cascades_per_launch;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_cascade_group(datum_ocean_t ctx, int *cascades_per_launch, int *launches_per_pass)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_cascade_group: null handle");
+
+  int const group = cascade_group(ctx);
+
+  if (cascades_per_launch) *cascades_per_launch = group;
+  if (launches_per_pass) *launches_per_pass = (ctx->cascades + group - 1) / group;
 
   return DATUM_OCEAN_OK;
 }
@@ -2023,9 +2159,14 @@ int datum_ocean_profile_begin(datum_ocean_t ctx, int max_steps, int stride)
   if (!ctx || max_steps < 1 || stride < 1)
     return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_profile_begin: bad argument");
 
+  if (ctx->literal)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_profile_begin: the handle is in the literal mode, whose dispatches are not sampled");
+
   HIPCHECK(ctx, hipSetDevice(ctx->device));
 
-  while ((int)ctx->events.size() < 4 * max_steps)
+  int const groups = (ctx->cascades + cascade_group(ctx) - 1) / cascade_group(ctx);
+
+  while (ctx->events.size() < (size_t)4 * max_steps * groups)
   {
     hipEvent_t e;
     HIPCHECK(ctx, hipEventCreate(&e));
@@ -2051,7 +2192,10 @@ int datum_ocean_profile_end(datum_ocean_t ctx, double *rowpass_ms, double *colpa
 
   double row = 0, col = 0;
 
-  for(int i = 0; i < ctx->profsteps; ++i)
+  // a sampled step = one launch of either pass per cascade group: the sums over a step's launches
+  int const groups = (ctx->cascades + cascade_group(ctx) - 1) / cascade_group(ctx);
+
+  for(int i = 0; i < ctx->profsteps * groups; ++i)
   {
     float ms;
     HIPCHECK(ctx, hipEventElapsedTime(&ms, ctx->events[4*i+0], ctx->events[4*i+1]));

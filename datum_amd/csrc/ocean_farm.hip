@@ -42,7 +42,7 @@ namespace ocean
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;             // optional
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;             // optional: the teardown of a communicator whose collective failed
     ncclResult_t (*AllGather)(void const*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     char const *(*GetErrorString)(ncclResult_t) = nullptr;
     char const *(*GetLastError)(ncclComm_t) = nullptr;           // optional: only adds RCCL's own text to an error
@@ -154,5 +154,6 @@ namespace ocean
     std::vector<FarmSlot> slots;
     int head = 0;                     // next slot
     unsigned long gathers = 0;
+    bool failed = false;              // a collective on this communicator returned an error: torn down with ncclCommAbort (a destroy waits for its operations)
   };
 }

@@ -65,7 +65,8 @@ namespace ocean
     cf const *tw;        // [N]                  exp(+2 pi i k / N)
     float const *omega;  // [cascade][(N/2+1)^2] dispersion(k) by (|m - N/2|, |n - N/2|)
     int ndt;
-    int cascades;
+    int cascades;        // cascades THIS launch works on ...
+    int first;           // ... starting with this one (the two passes are launched per group of cascades: ocean_capi, cascade_group)
     float dt[MAX_PENDING];
     CascadeConst casc[DATUM_OCEAN_MAX_CASCADES];
 #ifdef OCEAN_STAMPS
@@ -759,8 +760,10 @@ namespace ocean
 
     cf *midtab = reinterpret_cast<cf*>(smem);
 
+#ifndef OCEAN_EXP_INPUTS_FIRST
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
       midtab[i] = L::midtab_entry(a.tw, i);
+#endif
 
     // work items = (cascade, group of PAIRS row pairs), cascade-major; workgroup b takes items b, b + gridDim.x, ...
     // Neighbouring pairs read each other's rows as ocean.sim's mirror rows: item -> group deals contiguous bands of
@@ -796,7 +799,7 @@ namespace ocean
 
     auto request = [&](int item, int t, Inputs &in)
     {
-      int const cascade = item / G;
+      int const cascade = a.first + item / G;
       int const y = row_of(item);
 
       constexpr size_t QUAD = (size_t)(N / 2 + 1) * (N / 2 + 1);
@@ -831,10 +834,23 @@ namespace ocean
       }
     };
 
+#ifdef OCEAN_EXP_INPUTS_FIRST
+    Inputs in;
+
+    request((int)blockIdx.x, t_, in);
+
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+
     cf const ca_ = a.tw[t_];                  // exp(2 pi i t / N)
 
     typename LineTw<N, E>::type w_;
     LineTw<N, E>::load(a.tw, t_, w_);
+
+#ifdef OCEAN_EXP_INPUTS_FIRST
+    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
+      midtab[i] = L::midtab_entry(a.tw, i);
+#endif
 
 #ifdef OCEAN_STAMPS
     unsigned long long *stampbase = a.stamps + (size_t)blockIdx.x * 16;
@@ -850,7 +866,7 @@ namespace ocean
 
       OCEAN_STAMP(1);
 
-      int const cascade = item / G;
+      int const cascade = a.first + item / G;
       int const p = group_of(item) * C::PAIRS + pr;
       int const y = row_of(item);
       int const otherhalf = (p == 0) ? half : 1 - half;
@@ -1019,9 +1035,11 @@ namespace ocean
 
     int item = (int)blockIdx.x;
 
+#ifndef OCEAN_EXP_INPUTS_FIRST
     Inputs in;
 
     request(item, t_, in);
+#endif
 
     OCEAN_WAIT_LOADS();
 
@@ -1104,8 +1122,10 @@ namespace ocean
     cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [K][CS][W]
     float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [N][W], after the transforms
 
+#ifndef OCEAN_EXP_INPUTS_FIRST
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
       midtab[i] = L::midtab_entry(a.tw, i);
+#endif
 
     constexpr int NT = C::TILES;
 
@@ -1130,7 +1150,7 @@ namespace ocean
 
     auto request = [&](int item, int t, int cp, Raw (&q)[E])
     {
-      int const cascade = item / NT;
+      int const cascade = a.first + item / NT;
       int const x = tile_of(item) * W + cp;
 
       __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV const*>(a.spec) + cascade * plane, plane * sizeof(SV));
@@ -1171,8 +1191,21 @@ namespace ocean
     OCEAN_STAMP_WHERE();
     OCEAN_STAMP(0);
 
+#ifdef OCEAN_EXP_INPUTS_FIRST
+    Raw q[E];
+
+    request((int)blockIdx.x, t_, cp_, q);
+
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+
     typename LineTw<N, E>::type w_;
     LineTw<N, E>::load(a.tw, t_, w_);
+
+#ifdef OCEAN_EXP_INPUTS_FIRST
+    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
+      midtab[i] = L::midtab_entry(a.tw, i);
+#endif
 
     // One tile: `q` holds its values as loaded; when `more`, the next tile's values are requested into `q` again between
     // the last exchange and the last pass (registers are free there) and are in flight during the last pass, the map
@@ -1245,7 +1278,7 @@ namespace ocean
 
       OCEAN_STAMP(2);
 
-      int const cascade = item / NT;
+      int const cascade = a.first + item / NT;
       int const x = tile_of(item) * W + cp;
 
       CascadeConst const cc = a.casc[cascade];
@@ -1304,9 +1337,11 @@ namespace ocean
 
     int item = (int)blockIdx.x;
 
+#ifndef OCEAN_EXP_INPUTS_FIRST
     Raw q[E];
 
     request(item, t_, cp_, q);
+#endif
 
     OCEAN_WAIT_LOADS();
     OCEAN_STAMP(1);

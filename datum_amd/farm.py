@@ -108,13 +108,38 @@ def cu_masked_stream(device, mask):
     import ctypes
 
     hip = _hip()
-    words = (ctypes.c_uint32 * 8)(*[(mask >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+    # one mask word per 32 compute units of THIS device (256 on an MI355X: 8 words); bits beyond the device are dropped
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    nwords = max(1, (cus + 31) // 32)
+    mask &= (1 << cus) - 1
+    if mask == 0:
+        raise RuntimeError("cu_masked_stream: the mask selects no compute unit of this device")
+    words = (ctypes.c_uint32 * nwords)(*[(mask >> (32 * i)) & 0xFFFFFFFF for i in range(nwords)])
     handle = ctypes.c_void_p()
     with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), 8, words)
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), nwords, words)
     if rc != 0 or not handle.value:
         raise RuntimeError(f"hipExtStreamCreateWithCUMask: {rc}")
-    return torch.cuda.ExternalStream(handle.value, device=device)
+    stream = torch.cuda.ExternalStream(handle.value, device=device)
+    _MASKED_STREAMS[stream.cuda_stream] = handle.value       # torch does not own an external stream: release_cu_masked_stream destroys it
+    return stream
+
+
+_MASKED_STREAMS = {}
+
+
+def release_cu_masked_stream(stream):
+    """Destroys a stream made by cu_masked_stream once its work is done (torch never destroys an ExternalStream)."""
+    handle = _MASKED_STREAMS.pop(getattr(stream, "cuda_stream", None), None)
+    if handle:
+        stream.synchronize()
+        _hip().hipStreamDestroy(ctypes_void_p(handle))
+
+
+def ctypes_void_p(value):
+    import ctypes
+
+    return ctypes.c_void_p(value)
 
 
 class TileGather:
@@ -302,3 +327,9 @@ class TileGather:
                 if w is not None:
                     w.wait()
                     self.work[s] = None
+
+    def close(self):
+        """Waits for everything launched and destroys a CU-masked communication stream (torch does not own an external stream)."""
+        self.drain()
+        if self.cuda:
+            release_cu_masked_stream(self.comm)

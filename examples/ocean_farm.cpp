@@ -4,8 +4,9 @@
 // all-gather per batch through the C ABI (datum_ocean_farm_*).  No Python, no PyTorch, no MPI: the parent starts the ranks
 // as child processes BEFORE anything touches a GPU and relays rank 0's 128-byte communicator id over pipes.
 //
-// Usage: ocean_farm [ranks=1] [resolution=2048] [batches=3] [steps_per_batch=20] [payload: 1 xyz32 | 2 xyz16 | 0 maps] [comm_cus=32]
-// comm_cus: compute units the collective gets to itself (datum_ocean_farm_partition; 0 = both streams on the whole device)
+// Usage: ocean_farm [ranks=1] [resolution=2048] [batches=3] [steps_per_batch=20] [payload: 1 xyz32 | 2 xyz16 | 0 maps] [comm_cus=auto]
+// comm_cus: compute units the collective gets to itself (datum_ocean_farm_partition; 0 = both streams on the whole device; default: the
+// module's own share, an eighth of the device, skipped with a warning where it cannot be had)
 // Every rank prints one line per batch: a checksum of every tile of the gathered field (all ranks must print the same), and
 // whether its own tile in the gathered block equals what it packed.  Exit code 0 only if every rank succeeded.
 //
@@ -82,7 +83,14 @@ namespace
     CHECK(datum_ocean_farm_init(hip, id, sizeof(id), rank, world, format, 2));
 
     // the collective's copying workgroups on compute units of their own, the step's kernels on the others
-    if (commcus > 0)
+    // (the default asks for the module's own share and goes on unpartitioned where the device or the runtime has none to give -- a part with
+    // fewer than 64 compute units, a runtime without CU masks --; a share the user asked for by number must be granted)
+    if (commcus == DATUM_OCEAN_FARM_PARTITION_AUTO)
+    {
+      if (datum_ocean_farm_partition(hip, commcus) != DATUM_OCEAN_OK)
+        fprintf(stderr, "rank %d: no compute-unit partition (%s): both streams on the whole device\n", rank, datum_ocean_last_error(hip));
+    }
+    else if (commcus > 0)
       CHECK(datum_ocean_farm_partition(hip, commcus));
 
     size_t bytes = 0;
@@ -163,7 +171,7 @@ int main(int argc, char **argv)
   int batches = (argc > 3) ? atoi(argv[3]) : 3;
   int steps = (argc > 4) ? atoi(argv[4]) : 20;
   int format = (argc > 5) ? atoi(argv[5]) : DATUM_OCEAN_PAYLOAD_XYZ32;
-  int commcus = (argc > 6) ? atoi(argv[6]) : 32;
+  int commcus = (argc > 6) ? atoi(argv[6]) : DATUM_OCEAN_FARM_PARTITION_AUTO;
 
   if (world < 1 || world > 64)
     return 2;

@@ -40,7 +40,7 @@ extern "C" {
  *   4  round 4: ENOTREADY = -5, datum_ocean_map_layout gained texel_bytes, 24-byte texels in bound map buffers, farm entry points
  *   5  round 5: datum_ocean_abi_version, datum_ocean_export_maps, datum_ocean_set_literal_transform
  *   6  round 5: datum_ocean_farm_partition, datum_ocean_own_stream */
-#define DATUM_OCEAN_ABI_VERSION 6
+#define DATUM_OCEAN_ABI_VERSION 7
 int datum_ocean_abi_version(void);
 
 enum
@@ -131,7 +131,17 @@ int datum_ocean_set_spectrum_format(datum_ocean_t ctx, int format);
  * literal arithmetic by that table's own error (RMSE 1.4e-5 at 1024^2, 7e-5 at 4096^2; it is the one closer to a float64 transform).
  * 4-17 x slower than the fused step (tools/literal_bench.py), 24 * N * N bytes of extra device memory once switched on; phase, maps, gen, read_maps,
  * export_maps and the farm work as before.  Takes effect at the next datum_ocean_displace. */
-int datum_ocean_set_literal_transform(datum_ocean_t ctx, int on);
+int datum_ocean_set_literal_transform(datum_ocean_t ctx, int on);   /* DATUM_OCEAN_ESTATE while a profile is open or the spectrum format is FP16 (and those two refuse while the mode is on) */
+
+/* Cascades per launch of the two kernels (ABI 7).  The reference records one dispatch per shader for its one grid (ocean.cpp:769-789);
+ * a handle with several cascades launches row pass and column pass group by group -- row(g), column(g), row(g + 1), ... on the handle's
+ * stream -- so that the 16 bytes per point a group's row pass leaves for its column pass are still in the 256 MiB Infinity Cache when
+ * they are read.  0 (default): the largest group whose working set (52 bytes per point and cascade, 44 with the fp16 spectrum) fits the
+ * cache with room to spare -- 4 cascades at 1024^2, 1 from 2048^2 up, every cascade at once for smaller grids; n > 0: n cascades per
+ * launch (n >= cascades: one launch per pass, the form up to ABI 6).  Results do not depend on the group.  The getter reports the group in
+ * use and the launches per pass and displace call. */
+int datum_ocean_set_cascade_group(datum_ocean_t ctx, int cascades_per_launch);
+int datum_ocean_cascade_group(datum_ocean_t ctx, int *cascades_per_launch, int *launches_per_pass);
 
 int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, float const *phase);
 int datum_ocean_read_state(datum_ocean_t ctx, int cascade, float *phase);
@@ -232,9 +242,18 @@ int datum_ocean_farm_wait(datum_ocean_t ctx, int slot, float *collective_ms);
  *               recreated.  A handle that runs on a caller's stream (datum_ocean_set_stream) keeps it: hand it the own stream instead
  *   own_stream  the handle's own hipStream_t (e.g. to record events on it or to make it the current stream of a framework), valid until
  *               the next partition / shutdown / destroy
- * farm_shutdown undoes the partition. */
+ * farm_shutdown undoes the partition.
+ * NULL STREAM: hipExtStreamCreateWithCUMask takes no flags; the streams it makes report hipStreamDefault where this runtime says anything
+ * (farm_stream_flags below: 0 = hipStreamDefault = BLOCKING, 1 = hipStreamNonBlocking), i.e. unlike the hipStreamNonBlocking streams they
+ * replace they synchronise with the legacy null stream: an operation a caller puts on the null stream (a synchronous hipMemcpy, a
+ * framework's default stream) while the farm runs serialises the communication and the compute stream and costs the overlap the
+ * partition exists for -- results stay right.  The module itself never touches the null stream after datum_ocean_create (every copy,
+ * memset and kernel of every entry point is on the handle's stream or the communication stream: tests/test_golden_and_abi.py holds
+ * the sources to that); keep the caller's own work off it too while a partitioned farm is gathering. */
+#define DATUM_OCEAN_FARM_PARTITION_AUTO (-1)   /* comm_cus: an eighth of the device in whole shares of 8 (32 of 256); 0 on a device with fewer than 64 compute units */
 int datum_ocean_farm_partition(datum_ocean_t ctx, int comm_cus);
 int datum_ocean_own_stream(datum_ocean_t ctx, void **hip_stream);
+int datum_ocean_farm_stream_flags(datum_ocean_t ctx, unsigned int *communication_stream_flags, unsigned int *own_stream_flags);   /* hipStreamGetFlags of the two (ABI 7) */
 
 /* blocking read-backs (host pointers).  maps: 2*N*N*4 floats. */
 int datum_ocean_read_maps(datum_ocean_t ctx, int cascade, float *maps);
@@ -323,7 +342,8 @@ int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *c, float *d
  * begin: every `stride`-th displace call (at most max_samples of them) launches its two kernels with a start and a
  * stop event attached to the dispatch itself (hipExtLaunchKernel), i.e. each sampled kernel is timed from its first
  * to its last workgroup and nothing is inserted between the kernels; end: sync and return the mean kernel durations
- * in milliseconds and the number of displace calls sampled. */
+ * in milliseconds and the number of displace calls sampled.
+ * With several cascade groups per displace call (datum_ocean_set_cascade_group) a sample is the SUM over the call's launches of either kernel. */
 int datum_ocean_profile_begin(datum_ocean_t ctx, int max_samples, int stride);
 int datum_ocean_profile_end(datum_ocean_t ctx, double *rowpass_ms, double *colpass_ms, int *steps);
 

@@ -157,11 +157,32 @@ def test_abi_version_is_exported_and_checked(monkeypatch):
     from datum_amd import capi
 
     lib = capi.load()
-    assert lib.datum_ocean_abi_version() == capi.header_abi_version() >= 5
+    # the binding's constant, the header and the library agree (the binding does not read the header at run time: ADVICE r05)
+    assert lib.datum_ocean_abi_version() == capi.ABI_VERSION == capi.header_abi_version() >= 7
 
     # a library that reports another version is refused at load time, before any call goes through it
     monkeypatch.setattr(capi, "_lib", None)
-    monkeypatch.setattr(capi, "header_abi_version", lambda: lib.datum_ocean_abi_version() + 1)
+    monkeypatch.setattr(capi, "ABI_VERSION", lib.datum_ocean_abi_version() + 1)
     with pytest.raises(OSError, match="ABI version"):
         capi.load()
     monkeypatch.setattr(capi, "_lib", lib)
+
+
+def test_module_keeps_off_the_null_stream():
+    # datum_ocean_farm_partition replaces hipStreamNonBlocking streams by CU-masked ones, which synchronise with the legacy null stream
+    # (include/datum_ocean_hip.h): the module must not put anything there itself -- every copy, memset and synchronisation of every entry
+    # point names a stream.  The one exception is the twiddle upload inside datum_ocean_create, before any stream of the handle has work.
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hits = []
+    for name in ("ocean_capi.hip", "ocean_farm.hip", "ocean_gen.hip", "ocean_literal.hip", "ocean_kernels.hip"):
+        text = open(os.path.join(root, "datum_amd", "csrc", name)).read()
+        for m in re.finditer(r"\b(hipMemcpy|hipMemset|hipMemcpyDtoH|hipMemcpyHtoD|hipMemcpyDtoD|hipDeviceSynchronize)\s*\(", text):
+            line = text.count("\n", 0, m.start()) + 1
+            hits.append((name, line, m.group(1)))
+        # kernels are launched with an explicit stream argument (hipLaunchKernelGGL's fifth) or through launch(), never on stream 0
+        for m in re.finditer(r"hipLaunchKernelGGL\(([^;]*?)\);", text, re.S):
+            args = m.group(1)
+            assert re.search(r",\s*0,\s*(ctx->stream|stream|f->stream)\s*,", args) or "ctx->stream" in args or "stream" in args, (name, args[:80])
+    assert [h[2] for h in hits] == ["hipMemcpy"] and hits[0][0] == "ocean_capi.hip", hits

@@ -1209,9 +1209,16 @@ def test_native_farm_on_partitioned_compute_units(capi, oracle, torch):
                 with pytest.raises(capi.OceanError) as e:
                     oc.farm_partition(bad)
                 assert e.value.code == capi.EINVAL
+            assert oc.farm_stream_flags() == (1, 1)               # the unpartitioned streams are hipStreamNonBlocking
             for b in range(6):
                 if partition:
                     oc.farm_partition(partition[b % len(partition)])
+                    # CU-masked streams come without a flags argument: whatever the runtime reports is what the header documents --
+                    # 0 (hipStreamDefault: synchronises with the null stream) or 1; an undone partition is non-blocking again
+                    flags = oc.farm_stream_flags()
+                    assert all(f in (0, 1) for f in flags)
+                    if partition[b % len(partition)] == 0:
+                        assert flags == (1, 1)
                 # the handle runs on its own stream: a framework takes it from the module
                 with torch.cuda.stream(torch.cuda.ExternalStream(oc.own_stream(), device="cuda:0")):
                     for _ in range(3):
@@ -1233,6 +1240,67 @@ def test_native_farm_on_partitioned_compute_units(capi, oracle, torch):
         assert len(got) == len(plain)
         for b, (x, y) in enumerate(zip(got, plain)):
             assert torch.equal(x.cpu(), y.cpu()), (pattern, b)
+
+
+@pytest.mark.parametrize("N,C,half", [(256, 5, False), (1024, 8, False), (1024, 6, True), (2048, 2, False)])
+def test_cascade_groups_do_not_change_the_result(capi, oracle, N, C, half):
+    # datum_ocean_displace launches the two passes per GROUP of cascades (row(g), column(g), row(g + 1), ...: the exchange spectrum of a
+    # group stays in the Infinity Cache; replaces the one dispatch per shader of ocean.cpp:769-789).  Whatever the group -- the module's own
+    # choice, one cascade per launch, ragged last groups, every cascade at once (the form up to ABI 6) -- phase and maps are the same
+    # bits, and the profile's samples are per step (sums over a step's launches).
+    p = oracle.EXAMPLE
+    states = [make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c % 4]) for c in range(min(C, 4))]
+
+    def run(group):
+        with capi.Ocean(N, C) as oc:
+            oc.set_spectrum_format(half)
+            oc.set_cascade_group(group)
+            g, launches = oc.cascade_group()
+            assert launches == -(-C // g) and 1 <= g <= C
+            for c in range(C):
+                oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c % 4], p["choppiness"] + 0.05 * c)
+                oc.upload_state(c, states[c % len(states)])
+            oc.profile_begin(2, 1)
+            with pytest.raises(capi.OceanError) as e:
+                oc.set_cascade_group(1)                       # the samples of an open profile are per group
+            assert e.value.code == capi.ESTATE
+            for _ in range(2):
+                oc.update(DT)
+                oc.displace()
+            row_ms, col_ms, n = oc.profile_end()
+            assert n == 2 and row_ms > 0 and col_ms > 0
+            oc.update(DT)
+            oc.displace()
+            return (g, launches), [oc.read_state(c) for c in range(C)], [oc.read_maps(c) for c in range(C)]
+
+    (g0, l0), phase0, maps0 = run(C)                          # every cascade in one launch per pass
+    assert (g0, l0) == (C, 1)
+    auto = None
+    for group in (0, 1, 3, C + 5):
+        (g, launches), phase, maps = run(group)
+        if group == 0:
+            auto = (g, launches)
+        for c in range(C):
+            assert np.array_equal(phase[c], phase0[c]), (group, c)
+            assert np.array_equal(maps[c], maps0[c]), (group, c)
+    # the module's own groups: a working set of 52 (44: fp16 spectrum) bytes per point and cascade under 224 MB
+    want = max(1, min(C, int(224.0e6 // (N * N * (44 if half else 52)))))
+    assert auto == (want, -(-C // want)), auto
+    # ... and the last cascade against the oracle (a cascade of the LAST, ragged group)
+    c = C - 1
+    ph = np.zeros((N, N), np.float32)
+    for _ in range(3):
+        oracle.update(ph, oracle.CASCADE_WAVESCALES[c % 4], DT)
+    assert np.array_equal(phase0[c], ph)
+    if N <= 1024:
+        ref = oracle.displace(states[c % len(states)], ph, oracle.CASCADE_WAVESCALES[c % 4], p["choppiness"] + 0.05 * c, w=oracle.weights(N, reduced=True))
+        err = rmse(maps0[c][..., :3], ref[..., :3])
+        assert err < (2e-3 * float(np.abs(ref[..., :3]).max()) if half else 1e-5), err
+
+    with capi.Ocean(64, 1) as oc:
+        with pytest.raises(capi.OceanError) as e:
+            oc.set_cascade_group(-1)
+        assert e.value.code == capi.EINVAL
 
 
 def _device_view(torch, ptr, numel, dtype):
