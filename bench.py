@@ -128,6 +128,38 @@ def measured_traffic(kernel, workload):
     return None, None
 
 
+def committed_parity(N):
+    """Which oracle the timed path is exact against, for THIS resolution, from the newest committed table of `pytest tests -m gpu`
+    (profiles/r??_parity_table.txt, written by tests/conftest.py's report fixture on the MI355X): displacement RMSE of
+      * the fused kernels (what this line times) against the oracle with the reference's twiddle FORMULA at a reduced lane index
+        (mathematically the reference's table, accurately evaluated): north_star's 1e-5 holds at every N;
+      * the fused kernels against the oracle with the reference's LITERAL table (cos / sin at unreduced fp32 angles up to pi N,
+        src/renderer/ocean.cpp:694-695): above 1e-5 from N = 512 up -- the literal table's own error (DESIGN.md F6);
+      * the module's literal mode (datum_ocean_set_literal_transform: the reference's own radix-2 transforms and literal table on the
+        GPU, a validation mode this benchmark never runs) against that literal-table oracle.
+    bench.py cannot run the oracle inside the timed run (it is test infrastructure), so the figures are quoted, with their source."""
+    import glob
+    import re
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_table.txt")), reverse=True):
+        try:
+            text = open(path).read()
+        except OSError:
+            continue
+        d = re.search(rf"^displace N=\s*{N}\s+rmse vs reduced-table oracle: disp (\S+) .*?vs literal-table oracle \(ocean\.cpp:694\): disp (\S+) .*?float64 transform: hip (\S+) literal oracle (\S+)", text, re.M)
+        l = re.search(rf"^literal mode N=\s*{N}\s+rmse vs literal-table oracle: disp (\S+)", text, re.M)
+        if not d:
+            continue
+        return {"displacement_rmse": {"fused_vs_reduced_table_oracle": float(d.group(1)), "fused_vs_literal_table_oracle": float(d.group(2)),
+                                      "literal_mode_vs_literal_table_oracle": (float(l.group(1)) if l else None),
+                                      "fused_dz_vs_float64_transform": float(d.group(3)), "literal_table_oracle_dz_vs_float64_transform": float(d.group(4))},
+                "bar": 1e-5,
+                "timed_path": "fused kernels: within 1e-5 of the reduced-table oracle at every N; against the reference's LITERAL table the distance is that table's "
+                              "own error (1e-5 * N / 64 asserted); the literal mode meets 1e-5 against the literal table at every N and is never timed here",
+                "source": f"profiles/{os.path.basename(path)} (pytest tests -m gpu on the MI355X)"}
+    return None
+
+
 def lavapipe_probe(N):
     """north_star asks for the reference's shaders on the lavapipe software-Vulkan driver as the CPU baseline.  The
     reference's own shader files do not travel (no /root/reference on the GPU box) and only support N = 64;
@@ -776,6 +808,7 @@ def main():
                 "launches_timed": nprof,
                 "hbm_regime": regime,
             },
+            "parity": committed_parity(N),
             "compute_ms": compute_ms,
             "gather_ms": gather_ms,
             "gen": gen,

@@ -146,7 +146,18 @@ namespace
       g = (int)(CASCADE_GROUP_BYTES / per);
     }
 
-    return g < 1 ? 1 : (g > ctx->cascades ? ctx->cascades : g);
+    g = g < 1 ? 1 : (g > ctx->cascades ? ctx->cascades : g);
+
+    // the module's own choice: groups of equal size where the cascades allow it (six cascades as 3 + 3, not 4 + 2: a ragged last group is
+    // a short launch with the same fill and drain)
+    if (ctx->cascadegroup <= 0)
+    {
+      int const groups = (ctx->cascades + g - 1) / g;
+
+      g = (ctx->cascades + groups - 1) / groups;
+    }
+
+    return g;
   }
 
   template<int N, bool H16>
@@ -2142,10 +2153,27 @@ int datum_ocean_debug_rowpass(datum_ocean_t ctx, int cascade, float *c, float *d
 
   size_t const P = plane(ctx);
 
+  // The work spectrum belongs to a launch, not to a cascade (slot cascade - first of the group: ocean_kernels.hip), and the last displace may
+  // have left another cascade's values in the slot: the row pass of this one cascade once more -- no update pending, so the phase is neither
+  // advanced nor stored and the values are those of the last displace -- into slot 0
+  rc = size_spectrum_scale(ctx);
+  if (rc != DATUM_OCEAN_OK)
+    return rc;
+
+  {
+    StepArgs a = make_args(ctx, 0, nullptr);
+    a.first = cascade;
+    a.cascades = 1;
+
+    hipError_t le = hipSuccess;
+    DISPATCH_N(ctx->N, le = launch_rowpass<NN>(ctx, a, nullptr));
+    HIPCHECK(ctx, le);
+  }
+
   if (ctx->half)
-    hipLaunchKernelGGL(ocean_unpack_kernel<true>, dim3(1024), dim3(256), 0, ctx->stream, static_cast<ch const*>(ctx->spec) + (size_t)cascade * P, ctx->N, ctx->casc[cascade].specinv, ctx->scratch, ctx->scratch + P);
+    hipLaunchKernelGGL(ocean_unpack_kernel<true>, dim3(1024), dim3(256), 0, ctx->stream, static_cast<ch const*>(ctx->spec), ctx->N, ctx->casc[cascade].specinv, ctx->scratch, ctx->scratch + P);
   else
-    hipLaunchKernelGGL(ocean_unpack_kernel<false>, dim3(1024), dim3(256), 0, ctx->stream, static_cast<cd const*>(ctx->spec) + (size_t)cascade * P, ctx->N, 1.0f, ctx->scratch, ctx->scratch + P);
+    hipLaunchKernelGGL(ocean_unpack_kernel<false>, dim3(1024), dim3(256), 0, ctx->stream, static_cast<cd const*>(ctx->spec), ctx->N, 1.0f, ctx->scratch, ctx->scratch + P);
   HIPCHECK(ctx, hipGetLastError());
   HIPCHECK(ctx, hipMemcpyAsync(c, ctx->scratch, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHECK(ctx, hipMemcpyAsync(d, ctx->scratch + P, P * sizeof(cf), hipMemcpyDeviceToHost, ctx->stream));

@@ -60,7 +60,7 @@ namespace ocean
   {
     float2 const *h0;    // [cascade][N*N]       OceanSet::h0
     float *phase;        // [cascade][N*N]       OceanSet::phase
-    void *spec;          // [cascade][N*N]       work spectrum (replaces Spectrum::h, hx, hy), blocked layout: cd, or ch (fp16 variant)
+    void *spec;          // [cascade - first][N*N] work spectrum of THIS launch (replaces Spectrum::h, hx, hy), blocked layout: cd, or ch (fp16 variant)
     float4 *maps;        // [cascade][2*N*N]     displacementmap, 2 layers, 24-byte texels in patches (map_compact_a / map_compact_b)
     cf const *tw;        // [N]                  exp(+2 pi i k / N)
     float const *omega;  // [cascade][(N/2+1)^2] dispersion(k) by (|m - N/2|, |n - N/2|)
@@ -879,7 +879,9 @@ namespace ocean
       CascadeConst const cc = a.casc[cascade];
 
       __amdgpu_buffer_rsrc_t rphase = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
-      __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV*>(a.spec) + cascade * plane, plane * sizeof(SV));
+      // (the work spectrum is per LAUNCH: slot cascade - first.  Every cascade group writes and reads the same slots, which therefore stay in the
+      // Infinity Cache from one group to the next instead of going out to HBM and back once per cascade)
+      __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV*>(a.spec) + (cascade - a.first) * plane, plane * sizeof(SV));
 
       float ph[E];
       float2 hk[E], hm[E];
@@ -1153,7 +1155,7 @@ namespace ocean
       int const cascade = a.first + item / NT;
       int const x = tile_of(item) * W + cp;
 
-      __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV const*>(a.spec) + cascade * plane, plane * sizeof(SV));
+      __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV const*>(a.spec) + (cascade - a.first) * plane, plane * sizeof(SV));
 
       #pragma unroll
       for(int s = 0; s < E; ++s)

@@ -318,6 +318,46 @@ def test_literal_transform_mode_cascades_and_gen(capi, oracle, torch):
     assert float((np.abs(got - vwant) / (1 + np.abs(vwant))).max()) < 2e-4
 
 
+def test_four_cascades_1024_literal_mode_against_the_literal_oracle(capi, oracle, report):
+    # BASELINE.json configs[2] -- 1024^2 x 4 cascades in ONE handle, seeds 1000 + c, wave scales {22, 64, 176, 512} -- in the LITERAL mode
+    # against the oracle with the reference's literal twiddle table (ocean.cpp:686-700): north_star's 1e-5 on the displacement holds against
+    # the reference's own arithmetic for the headline workload in that mode, while the fused (timed) path's distance to the same oracle is
+    # the literal table's own error (bench.py's `parity` object quotes these lines)
+    N, C = 1024, 4
+    p = oracle.EXAMPLE
+    states = [make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c]) for c in range(C)]
+    steps = 3
+    with capi.Ocean(N, C) as oc:
+        for c in range(C):
+            oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c], p["choppiness"])
+            oc.upload_state(c, states[c])
+        oc.set_literal_transform(True)
+        for _ in range(steps):
+            oc.update(DT)
+            oc.displace()
+        got = [oc.read_maps(c) for c in range(C)]
+        gph = [oc.read_state(c) for c in range(C)]
+        oc.set_literal_transform(False)
+        oc.displace()                                  # the same states through the fused kernels (what bench.py times)
+        fused = [oc.read_maps(c) for c in range(C)]
+    w = oracle.weights(N)                              # the literal table
+    for c in range(C):
+        phase = np.zeros((N, N), np.float32)
+        for _ in range(steps):
+            oracle.update(phase, oracle.CASCADE_WAVESCALES[c], DT, mt=True)
+        assert np.array_equal(gph[c], phase), c
+        lit = oracle.displace(states[c], phase, oracle.CASCADE_WAVESCALES[c], p["choppiness"], w=w, mt=True)
+        scale = float(np.abs(lit[0]).max())
+        e_mode = [rmse(got[c][layer, ..., :3], lit[layer, ..., :3]) for layer in (0, 1)]
+        e_fused = [rmse(fused[c][layer, ..., :3], lit[layer, ..., :3]) for layer in (0, 1)]
+        report(f"1024^2 x 4 literal mode, cascade {c} (wavescale {oracle.CASCADE_WAVESCALES[c]:5.0f}): rmse vs literal-table oracle: disp {e_mode[0]:.3e} normal {e_mode[1]:.3e} "
+               f"| the fused path vs the same oracle: disp {e_fused[0]:.3e} normal {e_fused[1]:.3e} (largest |disp| {scale:.3e})")
+        assert e_mode[0] < 1e-5 and e_mode[1] < 1e-5, c                # north_star's bar against the reference's literal arithmetic
+        assert e_mode[0] < 2e-6 * max(1.0, scale), c
+        assert e_fused[0] < 1e-5 * N / 64 * max(1.0, scale), c         # the fused path: the literal table's own error (F6)
+        assert np.all(got[c][..., 3] == 0)
+
+
 def test_four_cascades_1024_against_oracle(capi, oracle, report):
     # BASELINE.json configs[2] as the bench runs it: 1024^2 x 4 cascades in ONE handle, seeds 1000 + c, wave scales
     # {22, 64, 176, 512}, each cascade against the oracle
@@ -1284,7 +1324,9 @@ def test_cascade_groups_do_not_change_the_result(capi, oracle, N, C, half):
             assert np.array_equal(phase[c], phase0[c]), (group, c)
             assert np.array_equal(maps[c], maps0[c]), (group, c)
     # the module's own groups: a working set of 52 (44: fp16 spectrum) bytes per point and cascade under 224 MB
-    want = max(1, min(C, int(224.0e6 // (N * N * (44 if half else 52)))))
+    # ... in groups of equal size where the cascades allow it (six as 3 + 3)
+    fit = max(1, min(C, int(224.0e6 // (N * N * (44 if half else 52)))))
+    want = -(-C // -(-C // fit))
     assert auto == (want, -(-C // want)), auto
     # ... and the last cascade against the oracle (a cascade of the LAST, ragged group)
     c = C - 1

@@ -11,6 +11,7 @@
 // H0B = bytes per h0 value as stored (8: float2; 4: two halves -- SURVEY.md 8d's own count for configs[4] has 4).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include "../../datum_amd/csrc/ocean_kernels.hip"
 using namespace ocean;
 #define CK(x) do { hipError_t e=(x); if(e!=hipSuccess){printf("%s: %s\n",#x,hipGetErrorString(e)); return 1;} } while(0)
@@ -60,6 +61,48 @@ __global__ void __launch_bounds__(THREADS, MINWAVES) rowskel(void const* __restr
       u2 d = { __float_as_uint(ax + bx), __float_as_uint(ph[s] * om[s]) };
       __builtin_amdgcn_raw_buffer_store_b64(d, rsp, (int)blocked<N>(y, x) * 8, 0, SPEC_STORE_AUX); }
   }
+}
+
+
+// S: the kernel's shape once more (512-thread pair, fp32 h0, 2 workgroups per CU) with ONE thing changed at a time: which of its six streams is the slow one?
+//   DROP bit 0 phase loads, 1 own h0 loads, 2 mirror h0 loads, 3 dispersion loads, 4 phase stores, 5 spectrum stores
+//   PAUX / SAUX: cache policy of the phase / spectrum stores (17 = sc0 sc1 written through: what ships; 0 plain; 2 nt)
+//   LAYOUT 0: 8 x 8 blocks (64-byte block rows with the 8-byte fp16 value: what ships), 1: 8 rows x 16 columns (128-byte block rows), 2: row-major
+template<int DROP, int PAUX, int SAUX, int LAYOUT>
+__global__ void __launch_bounds__(512, 4) rowvar(float2 const* __restrict__ h0, float* __restrict__ phase, float const* __restrict__ omega, u2* __restrict__ spec, int delay) {
+  extern __shared__ unsigned char occupancy_cap[];
+  int const p = pair_of(blockIdx.x);
+  size_t const plane = (size_t)N * N;
+  __amdgpu_buffer_rsrc_t rph = make_rsrc(phase, plane * 4), rsp = make_rsrc(spec, plane * 8);
+  int const half = threadIdx.x / T, t = threadIdx.x % T;
+  int const y = half ? (p == 0 ? N / 2 : N - p) : p;
+  int const i = abs(y - N / 2);
+  float ph[E], om[E]; float2 a[E], b[E];
+  __amdgpu_buffer_rsrc_t rh0 = make_rsrc(h0, plane * 8), rom = make_rsrc(omega, (size_t)Q * Q * 4);
+  int const e0 = y * N + t, m0 = (N - 1 - y) * N + (N - 1 - t - T * (E - 1));
+  int const lower = (i * Q + N / 2 - t - T * (E / 2 - 1)) * 4, upper = (i * Q + t) * 4;
+  #pragma unroll
+  for (int s = 0; s < E; ++s) {
+    ph[s] = (DROP & 1) ? (float)t : buf_load_f32(rph, e0 * 4, T * s * 4);
+    a[s] = (DROP & 2) ? make_float2(t, s) : buf_load_f32x2(rh0, e0 * 8, T * s * 8);
+    b[s] = (DROP & 4) ? make_float2(s, t) : buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
+    om[s] = (DROP & 8) ? (float)s : ((s < E / 2) ? buf_load_f32(rom, lower, T * (E / 2 - 1 - s) * 4) : buf_load_f32(rom, upper, T * (s - E / 2) * 4));
+  }
+  if (!(DROP & 16)) {
+    #pragma unroll
+    for (int s = 0; s < E; ++s) { int x = t + T * s; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ph[s] + om[s]), rph, (y * N + x) * 4, 0, PAUX); }
+  }
+  if (delay > 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); idle(delay); }
+  float keep = 0;
+  #pragma unroll
+  for (int s = 0; s < E; ++s) { int x = t + T * s;
+    u2 d = { __float_as_uint(a[s].x + a[s].y + b[s].x - b[s].y), __float_as_uint(ph[s] * om[s]) };
+    int at;
+    if (LAYOUT == 0) at = (int)blocked<N>(y, x);
+    else if (LAYOUT == 1) { int const B = 128; at = (x / B) * N * B + ((y / 8) * (B / 16) + (x % B) / 16) * 128 + (y % 8) * 16 + (x % 16); }
+    else at = y * N + x;
+    if (!(DROP & 32)) __builtin_amdgcn_raw_buffer_store_b64(d, rsp, at * 8, 0, SAUX); else keep += __uint_as_float(d.x) + __uint_as_float(d.y); }
+  if ((DROP & 32) && keep == 12345.678f) phase[0] = keep;
 }
 
 // P: persistent, 1024 threads (16 waves) per CU, pairs b, b + gridDim.x, ...  LDS: phase rows 2 x 16 KB + own h0 rows 2 x (4096 x H0B)
@@ -148,8 +191,31 @@ int main() {
   #define ATTR(k) hipFuncSetAttribute(reinterpret_cast<void const*>(&k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)
   ATTR((rowskel<512, 8, 4>)); ATTR((rowskel<512, 4, 4>)); ATTR((rowskel<512, 4, 6>)); ATTR((rowskel<256, 8, 4>)); ATTR((rowskel<256, 4, 4>)); ATTR((rowwalk<8>)); ATTR((rowwalk<4>));
   double const B8 = 24.0 * plane, B4 = 20.0 * plane;     // HBM bytes by design: h0 8 (4) + phase 4 + 4 + spectrum 8
-  char name[200];
-  for (int rep = 0; rep < 2; ++rep) {
+  char name[240];
+  #define SVAR(DROP, PAUX, SAUX, LAYOUT, what) do { ATTR((rowvar<DROP, PAUX, SAUX, LAYOUT>)); for (int delay : {0, 30}) { \
+      snprintf(name, sizeof(name), "S: %s, %4.1f us idle", what, delay * 0.427); \
+      timeit(name, B8, [&]{ hipLaunchKernelGGL((rowvar<DROP, PAUX, SAUX, LAYOUT>), dim3(N/2), dim3(512), cap(2, 0), 0, (float2 const*)h0, phase, omega, spec, delay); }); } } while(0)
+  if (getenv("SKEL_STREAMS")) for (int rep = 0; rep < 2; ++rep) {
+    SVAR(0, 17, 17, 0, "what ships (phase and spectrum stores written through, 8 x 8 blocks)");
+    SVAR(1, 17, 17, 0, "without the phase loads");
+    SVAR(2, 17, 17, 0, "without the own h0 loads");
+    SVAR(4, 17, 17, 0, "without the mirror h0 loads");
+    SVAR(8, 17, 17, 0, "without the dispersion loads");
+    SVAR(16, 17, 17, 0, "without the phase stores");
+    SVAR(32, 17, 17, 0, "without the spectrum stores");
+    SVAR(48, 17, 17, 0, "without any store");
+    SVAR(15, 17, 17, 0, "without any load");
+    SVAR(0, 0, 17, 0, "phase stores plain");
+    SVAR(0, 17, 0, 0, "spectrum stores plain");
+    SVAR(0, 0, 0, 0, "both store streams plain");
+    SVAR(0, 2, 2, 0, "both store streams nt");
+    SVAR(0, 17, 17, 1, "spectrum in 8 x 16 blocks (128-byte block rows), written through");
+    SVAR(0, 17, 0, 1, "spectrum in 8 x 16 blocks, plain");
+    SVAR(0, 0, 0, 1, "spectrum in 8 x 16 blocks, both store streams plain");
+    SVAR(0, 17, 17, 2, "spectrum row-major, written through");
+    SVAR(0, 0, 0, 2, "spectrum row-major, both store streams plain");
+  }
+  if (!getenv("SKEL_STREAMS")) for (int rep = 0; rep < 2; ++rep) {
     for (int delay : {0, 15, 30}) {
       snprintf(name, sizeof(name), "K: 512-thread pair, fp32 h0, 2 workgroups per CU (the kernel's shape), %4.1f us idle between inputs and spectrum stores", delay * 0.427);
       timeit(name, B8, [&]{ hipLaunchKernelGGL((rowskel<512, 8, 4>), dim3(N/2), dim3(512), cap(2, 0), 0, h0, phase, omega, spec, delay); });
