@@ -127,37 +127,32 @@ namespace
     return a;
   }
 
-  // Cascades per launch of the two passes.  Between the passes 16 bytes per point (8: fp16 spectrum) are written and read back once; with every
-  // cascade of the handle in one launch per pass that exchange goes out to HBM and comes back as soon as the handle's working set --
-  // h0 8 + phase 4 + work spectrum 16 + maps 24 bytes per point -- is beyond the 256 MiB Infinity Cache (from x 8 at 1024^2, from x 2 at
-  // 2048^2).  Launched group by group -- row(g), column(g), row(g + 1), ... on the same stream -- a group's spectrum is still in the cache
-  // when its column pass reads it.  The group is the largest whose own working set fits with room to spare (4 cascades at 1024^2, 1 from
-  // 2048^2 up); measured in profiles/r06_cascade_groups.txt.  Replaces the one dispatch per shader of ocean.cpp:769-789.
-  constexpr double CASCADE_GROUP_BYTES = 224.0e6;
+  // Cascades per launch of the two passes (replaces the one dispatch per shader of ocean.cpp:769-789).  A handle whose working set is resident
+  // in the Infinity Cache takes every cascade in one launch per pass.  Beyond it the maps are streamed (ocean_kernels.hip: MAP_STORE_AUX) and
+  // what can stay in the cache from the row pass to the column pass -- and for h0 and the phase from step to step -- is h0 8 + phase 4 + work
+  // spectrum 16 (8: fp16) bytes per point: the passes are launched group by group -- row(g), column(g), row(g + 1), ... on the same stream,
+  // the work spectrum's slots reused from group to group -- with the largest group whose share of that fits: 8 cascades of 1024^2, 2 of 2048^2,
+  // 1 of 4096^2; groups of equal size where the cascades allow it (twelve as 6 + 6).  Measured (profiles/r06_cascade_groups.txt): 1024^2 x 16
+  // as 2 x 8 77.8 k grids/s against 66.7 k in one launch and 71.1 k as 4 x 4; x 12 as 2 x 6 80.6 k against 74.2 k; x 8 in one launch 82.6 k
+  // against 78.3 k as 2 x 4; 2048^2 x 4 as 2 x 2 18.2 k against 16.0 k in one launch and 17.2 k as 4 x 1.
+  constexpr double CASCADE_GROUP_BYTES = 240.0e6;
 
   int cascade_group(datum_ocean_ctx const *ctx)
   {
     int g = ctx->cascadegroup;
 
-    if (g <= 0)
-    {
-      double const per = (double)plane(ctx) * (12.0 + (ctx->half ? 8.0 : 16.0) + 24.0);
+    if (g > 0)
+      return g > ctx->cascades ? ctx->cascades : g;
 
-      g = (int)(CASCADE_GROUP_BYTES / per);
-    }
+    if (!maps_stream(ctx->N, ctx->cascades, ctx->half))
+      return ctx->cascades;
 
+    g = (int)(CASCADE_GROUP_BYTES / ((double)plane(ctx) * (12.0 + (ctx->half ? 8.0 : 16.0))));
     g = g < 1 ? 1 : (g > ctx->cascades ? ctx->cascades : g);
 
-    // the module's own choice: groups of equal size where the cascades allow it (six cascades as 3 + 3, not 4 + 2: a ragged last group is
-    // a short launch with the same fill and drain)
-    if (ctx->cascadegroup <= 0)
-    {
-      int const groups = (ctx->cascades + g - 1) / g;
+    int const groups = (ctx->cascades + g - 1) / g;
 
-      g = (ctx->cascades + groups - 1) / groups;
-    }
-
-    return g;
+    return (ctx->cascades + groups - 1) / groups;
   }
 
   template<int N, bool H16>
@@ -178,7 +173,7 @@ namespace
     if (e != hipSuccess)
       return e;
 
-    if constexpr (col_has_plain_variant<N>())
+    if constexpr (col_has_stream_variant<N>())
       e = hipFuncSetAttribute(colpass_entry<N, H16, true>(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ColCfg<N>::LDS);
 
     return e;
@@ -241,9 +236,10 @@ namespace
     void *args[] = { &a };
     void const *kernel = ctx->half ? colpass_entry<N, true>() : colpass_entry<N, false>();
 
-    if constexpr (col_has_plain_variant<N>())
+    // the maps streamed instead of written through where the HANDLE's working set is beyond the Infinity Cache (whatever this launch's share of it)
+    if constexpr (col_has_stream_variant<N>())
     {
-      if (col_plain_maps<N>(ctx->cascades))
+      if (col_streams_maps<N>(ctx->cascades, ctx->half))
         kernel = ctx->half ? colpass_entry<N, true, true>() : colpass_entry<N, false, true>();
     }
 

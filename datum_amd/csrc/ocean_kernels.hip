@@ -211,9 +211,15 @@ namespace ocean
   //   map stores written through leave the XCD's L2 to the spectrum lines that neighbouring tiles share: column pass 36.7 -> 35.1 us at
   //   1024^2 x 4 (nt on the same stores 44.5 us, nt on the spectrum loads 44.4 us); the row pass with both of its store streams written
   //   through: 29.4 -> 28.4 us (either one alone: no change); loads: nothing gains, nt on h0 loses 6 us (the mirror read no longer
-  //   finds the row in L2): profiles/r04_store_policy_sweep.txt, r04_load_policy_sweep.txt.  At 4096^2, and from two cascades of 2048^2
-  //   on, the maps are far beyond the Infinity Cache and written-through map stores cost 2x: plain there (MAP_STORE_AUX_BIG).
-  constexpr int MAP_STORE_AUX = 17, MAP_STORE_AUX_BIG = 0, PHASE_STORE_AUX = 17, SPEC_STORE_AUX = 17;
+  //   finds the row in L2): profiles/r04_store_policy_sweep.txt, r04_load_policy_sweep.txt.
+  //   Round 6 (profiles/r06_store_policies.txt): where the handle's working set does NOT fit the 256 MiB Infinity Cache the maps are
+  //   STREAMED (nt): they are the one stream nobody reads again before it has left the cache anyway, and stored any other way -- plain
+  //   through round 5, written through -- their 24 bytes per point push the next ROW pass's inputs and the exchange spectrum out of it:
+  //   4096^2 fp16 row pass 118-120 -> 100-104 us and column pass 133 -> 115-122 us (the row pass gains although only the column pass's
+  //   instruction changed), 2048^2 x 4 15.9 -> 17.1 k grids/s, 1024^2 x 8 68.8 -> 77.9-78.4 k (its row pass 63 -> 48 us: the 164 MB of h0,
+  //   phase and one group's spectrum then STAY in the cache), x 6 68 -> 75 k, x 16 +1.5 %.  nt on the row pass's own stores loses at every
+  //   size (4096^2: 120 -> 128 us; 1024^2 x 16: 68.5 -> 60.5 k), sc1 alone and plain equal each other, written through + nt equals nt.
+  constexpr int MAP_STORE_AUX = 17, MAP_STORE_AUX_STREAM = 2, PHASE_STORE_AUX = 17, SPEC_STORE_AUX = 17;
 
   //|---------------------- update_ocean --------------------------------------
 
@@ -760,10 +766,8 @@ namespace ocean
 
     cf *midtab = reinterpret_cast<cf*>(smem);
 
-#ifndef OCEAN_EXP_INPUTS_FIRST
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
       midtab[i] = L::midtab_entry(a.tw, i);
-#endif
 
     // work items = (cascade, group of PAIRS row pairs), cascade-major; workgroup b takes items b, b + gridDim.x, ...
     // Neighbouring pairs read each other's rows as ocean.sim's mirror rows: item -> group deals contiguous bands of
@@ -834,23 +838,10 @@ namespace ocean
       }
     };
 
-#ifdef OCEAN_EXP_INPUTS_FIRST
-    Inputs in;
-
-    request((int)blockIdx.x, t_, in);
-
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-
     cf const ca_ = a.tw[t_];                  // exp(2 pi i t / N)
 
     typename LineTw<N, E>::type w_;
     LineTw<N, E>::load(a.tw, t_, w_);
-
-#ifdef OCEAN_EXP_INPUTS_FIRST
-    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
-      midtab[i] = L::midtab_entry(a.tw, i);
-#endif
 
 #ifdef OCEAN_STAMPS
     unsigned long long *stampbase = a.stamps + (size_t)blockIdx.x * 16;
@@ -1037,11 +1028,9 @@ namespace ocean
 
     int item = (int)blockIdx.x;
 
-#ifndef OCEAN_EXP_INPUTS_FIRST
     Inputs in;
 
     request(item, t_, in);
-#endif
 
     OCEAN_WAIT_LOADS();
 
@@ -1097,15 +1086,27 @@ namespace ocean
   // them 208 -> 187 us and 248 -> 259 us (not every step of this was a gain on its own)
   template<int N, bool H16> constexpr bool col_walks() { return N >= 4096; }
 
-  // PLAIN: the maps' stores are not written through (col_plain_maps: the sizes at which several cascades' maps are far
-  // beyond the Infinity Cache although one cascade's are not; the policy is part of the instruction, hence a template flag)
-  template<int N> constexpr bool col_has_plain_variant() { return N == 2048; }
+  // STREAM: the maps' stores are streamed (nt) instead of written through -- where the handle's working set (h0 8 + phase 4 + work spectrum
+  // 16 or 8 + maps 24 bytes per point and cascade) is beyond the Infinity Cache; the policy is part of the instruction, hence a template
+  // flag.  4096^2 always streams (one cascade is 0.9 GB); grids below 1024^2 never do (sixteen cascades of 512^2 still fit).
+  template<int N> constexpr bool col_has_stream_variant() { return N == 1024 || N == 2048; }
 
-  // 2048^2: one cascade (134 MB of maps) keeps the written-through stores, two or more plain ones (x 2: column pass
-  // 79 -> 75 us, x 4: 167.5 -> 160.8 us; x 1: 36.5 -> 37 us; 1024^2 x 8 / x 16: no difference) -- profiles/r02_4096_second_pass.txt
-  template<int N> inline bool col_plain_maps(int cascades) { return col_has_plain_variant<N>() && cascades >= 2; }
+  // the working set up to which writing the maps through wins: 1024^2 x 4 (218 MB) 82.4 k grids/s written through against 78.9 k streamed, x 5
+  // (272 MB) 72.4-74.0 against 72.1-72.5 k, x 6 (327 MB) 68.8 against 76.1 k; 2048^2 x 1 and the fp16 spectrum's x 4 / x 6 (185 / 277 MB)
+  // written through by 0-3 % (profiles/r06_store_policies.txt)
+  constexpr double MAPS_RESIDENT_BYTES = 300.0e6;
 
-  template<int N, bool H16, bool PLAIN>
+  inline bool maps_stream(int N, int cascades, bool half)
+  {
+    return N >= 4096 || (N >= 1024 && (double)cascades * N * N * (half ? 44.0 : 52.0) > MAPS_RESIDENT_BYTES);
+  }
+
+  template<int N> inline bool col_streams_maps(int cascades, bool half)
+  {
+    return col_has_stream_variant<N>() && maps_stream(N, cascades, half);
+  }
+
+  template<int N, bool H16, bool STREAM>
   __device__ __forceinline__ void colpass_body(StepArgs const &a)
   {
     typedef ColCfg<N> C;
@@ -1124,10 +1125,8 @@ namespace ocean
     cf *lines = reinterpret_cast<cf*>(smem + C::OFF_MAIN);            // [K][CS][W]
     float *dzmain = reinterpret_cast<float*>(smem + C::OFF_MAIN);     // [N][W], after the transforms
 
-#ifndef OCEAN_EXP_INPUTS_FIRST
     for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
       midtab[i] = L::midtab_entry(a.tw, i);
-#endif
 
     constexpr int NT = C::TILES;
 
@@ -1193,21 +1192,8 @@ namespace ocean
     OCEAN_STAMP_WHERE();
     OCEAN_STAMP(0);
 
-#ifdef OCEAN_EXP_INPUTS_FIRST
-    Raw q[E];
-
-    request((int)blockIdx.x, t_, cp_, q);
-
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-
     typename LineTw<N, E>::type w_;
     LineTw<N, E>::load(a.tw, t_, w_);
-
-#ifdef OCEAN_EXP_INPUTS_FIRST
-    for(int i = threadIdx.x; i < L::MIDTAB; i += C::THREADS)
-      midtab[i] = L::midtab_entry(a.tw, i);
-#endif
 
     // One tile: `q` holds its values as loaded; when `more`, the next tile's values are requested into `q` again between
     // the last exchange and the last pass (registers are free there) and are in flight during the last pass, the map
@@ -1311,9 +1297,8 @@ namespace ocean
 
       constexpr int SLOTBYTES = (T / map_patch_rows(N)) * map_compact_patchrow_bytes(N);
 
-      // (at 4096^2, where the 403 MB of maps are far beyond the Infinity Cache, writing through costs 2x: 487-525 us against
-      // 250-260 us in round 2's layouts)
-      constexpr int MAPAUX = (N <= 2048 && !PLAIN) ? MAP_STORE_AUX : MAP_STORE_AUX_BIG;
+      // (written through while the handle's working set is resident in the Infinity Cache, streamed beyond it: MAP_STORE_AUX above)
+      constexpr int MAPAUX = (N <= 2048 && !STREAM) ? MAP_STORE_AUX : MAP_STORE_AUX_STREAM;
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
@@ -1339,11 +1324,9 @@ namespace ocean
 
     int item = (int)blockIdx.x;
 
-#ifndef OCEAN_EXP_INPUTS_FIRST
     Raw q[E];
 
     request(item, t_, cp_, q);
-#endif
 
     OCEAN_WAIT_LOADS();
     OCEAN_STAMP(1);
@@ -1367,10 +1350,10 @@ namespace ocean
     }
   }
 
-  template<int N, bool H16, bool PLAIN = false>
+  template<int N, bool H16, bool STREAM = false>
   __global__ void OCEAN_LDS_UNPAIRED __launch_bounds__(ColCfg<N>::THREADS, ColCfg<N>::MIN_WAVES) ocean_colpass_kernel(StepArgs a)
   {
-    colpass_body<N, H16, PLAIN>(a);
+    colpass_body<N, H16, STREAM>(a);
   }
 
   // The same kernel with hipcc's pairing of LDS accesses left on.  1024^2 only: there the column pass (16 points per thread, 37 KB of
@@ -1381,21 +1364,21 @@ namespace ocean
 
   namespace paired
   {
-    template<int N, bool H16, bool PLAIN = false>
+    template<int N, bool H16, bool STREAM = false>
     __global__ void __launch_bounds__(ColCfg<N>::THREADS, ColCfg<N>::MIN_WAVES) ocean_colpass_kernel(StepArgs a)
     {
-      colpass_body<N, H16, PLAIN>(a);
+      colpass_body<N, H16, STREAM>(a);
     }
   }
 
   // the column-pass kernel the module launches at this resolution
-  template<int N, bool H16, bool PLAIN = false>
+  template<int N, bool H16, bool STREAM = false>
   inline void const *colpass_entry()
   {
     if constexpr (col_pairs_lds<N>())
-      return reinterpret_cast<void const*>(&paired::ocean_colpass_kernel<N, H16, PLAIN>);
+      return reinterpret_cast<void const*>(&paired::ocean_colpass_kernel<N, H16, STREAM>);
     else
-      return reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H16, PLAIN>);
+      return reinterpret_cast<void const*>(&ocean_colpass_kernel<N, H16, STREAM>);
   }
 
   // blocked packed spectrum -> two row-major complex planes (datum_ocean_debug_rowpass)

@@ -133,13 +133,14 @@ int datum_ocean_set_spectrum_format(datum_ocean_t ctx, int format);
  * export_maps and the farm work as before.  Takes effect at the next datum_ocean_displace. */
 int datum_ocean_set_literal_transform(datum_ocean_t ctx, int on);   /* DATUM_OCEAN_ESTATE while a profile is open or the spectrum format is FP16 (and those two refuse while the mode is on) */
 
-/* Cascades per launch of the two kernels (ABI 7).  The reference records one dispatch per shader for its one grid (ocean.cpp:769-789);
- * a handle with several cascades launches row pass and column pass group by group -- row(g), column(g), row(g + 1), ... on the handle's
- * stream -- so that the 16 bytes per point a group's row pass leaves for its column pass are still in the 256 MiB Infinity Cache when
- * they are read.  0 (default): the largest group whose working set (52 bytes per point and cascade, 44 with the fp16 spectrum) fits the
- * cache with room to spare -- 4 cascades at 1024^2, 1 from 2048^2 up, every cascade at once for smaller grids; n > 0: n cascades per
- * launch (n >= cascades: one launch per pass, the form up to ABI 6).  Results do not depend on the group.  The getter reports the group in
- * use and the launches per pass and displace call. */
+/* Cascades per launch of the two kernels (ABI 7).  The reference records one dispatch per shader for its one grid (ocean.cpp:769-789).
+ * A handle whose working set (52 bytes per point and cascade, 44 with the fp16 spectrum) is resident in the 256 MiB Infinity Cache takes
+ * every cascade in one launch per kernel.  Beyond that the maps are streamed past the cache and row pass and column pass are launched
+ * group by group -- row(g), column(g), row(g + 1), ... on the handle's stream -- so that what a group's row pass leaves for its column pass
+ * (and h0 and the phase from step to step) stays in the cache: 0 (default) = the module's choice, the largest group whose 28 (20) bytes
+ * per point fit -- 8 cascades of 1024^2, 2 of 2048^2, 1 of 4096^2 -- in groups of equal size; n > 0: n cascades per launch (n >= cascades:
+ * one launch per kernel).  Results do not depend on the group.  The getter reports the group in use and the launches per kernel and
+ * displace call. */
 int datum_ocean_set_cascade_group(datum_ocean_t ctx, int cascades_per_launch);
 int datum_ocean_cascade_group(datum_ocean_t ctx, int *cascades_per_launch, int *launches_per_pass);
 
