@@ -19,7 +19,13 @@
 #if defined(__HIPCC__)
 #define OC_HD __host__ __device__ __forceinline__
 #define OC_UNROLL _Pragma("unroll")
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
+#define OC_SCHED_FENCE() do { } while(0)
+#endif
+#else
+#define OC_SCHED_FENCE() do { } while(0)
 #define OC_HD inline
 #define OC_UNROLL
 #endif
@@ -510,6 +516,12 @@ namespace ocean
     static constexpr int RL = P::RL;
     static constexpr int M = P::M;
 
+#ifdef OCEAN_EXP_NO_FENCE
+    static constexpr bool FENCE_LAST_TASKS = false;
+#else
+    static constexpr bool FENCE_LAST_TASKS = (N == 2048 && W == 4 && E_ == 16);
+#endif
+
     // exchange 0: transposed, TP elements per q
     static constexpr int TP = T + lds_pad0(E, W);
 
@@ -653,6 +665,12 @@ namespace ocean
         OC_UNROLL
         for(int q = 0; q < RL; ++q)
           v[m + q * M] = u[q];
+
+        // the tasks of the last pass one after the other: hipcc otherwise starts task m + 1's LDS reads and twiddle powers under the tail of
+        // task m, and in the one kernel that sits at its register limit -- the 2048^2 column pass: 16 points per thread twice, two 512-thread
+        // tiles per CU = 128 registers -- two of task m's results went to scratch for it (20 bytes per lane through round 5)
+        if (FENCE_LAST_TASKS && m + 1 < M)
+          OC_SCHED_FENCE();
       }
     }
   };

@@ -139,7 +139,8 @@ struct OceanContext
 
   bool spectrumfp16 = false;              // extension: store the module's work spectrum as halves (set before prepare_ocean_context)
   bool literaltransform = false;          // validation: displace through the reference's own radix-2 transforms and literal twiddle table
-                                          // (datum_ocean_set_literal_transform; set before prepare_ocean_context) -- for texel-for-texel A/B with the Vulkan build
+                                          // (datum_ocean_set_literal_transform; set before prepare_ocean_context) -- for texel-for-texel A/B with the Vulkan build;
+                                          // not together with spectrumfp16 (the mode is the reference's fp32 arithmetic: prepare_ocean_context throws)
 
   datum_ocean_t hip = nullptr;            // replaces vulkan / pipelines / oceanset / spectrum / displacementmap
 

@@ -257,8 +257,24 @@ def test_literal_transform_mode_against_the_literal_oracle(capi, oracle, report,
             oc.displace()
         got = oc.read_maps(0)
         gphase = oc.read_state(0)
+        # (ABI 7, ADVICE r05: what belongs to the fused kernels -- the fp16 spectrum format, the profile's samples -- is refused in this mode
+        # rather than ignored, and the mode is refused while either is on)
+        for call in (lambda: oc.set_spectrum_format(True), lambda: oc.profile_begin(4)):
+            with pytest.raises(capi.OceanError) as e:
+                call()
+            assert e.value.code == capi.ESTATE
         oc.set_literal_transform(False)
+        oc.set_spectrum_format(True)
+        with pytest.raises(capi.OceanError) as e:
+            oc.set_literal_transform(True)
+        assert e.value.code == capi.ESTATE
+        oc.set_spectrum_format(False)
+        oc.profile_begin(4)
+        with pytest.raises(capi.OceanError) as e:
+            oc.set_literal_transform(True)
+        assert e.value.code == capi.ESTATE
         oc.displace()                                  # the same state through the fused kernels
+        assert oc.profile_end()[2] == 1
         fused = oc.read_maps(0)
         oc.set_literal_transform(True)
         oc.displace()

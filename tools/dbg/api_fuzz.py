@@ -76,7 +76,7 @@ for q in range(sequences):
                 e = rmse(got[0][..., :3], ref[0][..., :3]) / big
                 en = float(np.abs(got[1][..., :3] - ref[1][..., :3]).max())
                 assert np.isfinite(got).all() and np.all(got[..., 3] == 0), (q, log[-12:])
-                coarse = half and not literal       # (the literal mode has its own fp32 fields: the spectrum format does not reach it)
+                coarse = half                       # (never together with the literal mode: the two refuse each other)
                 assert e < (2e-3 if coarse else 2e-6), (q, "maps", c, e, half, literal, log[-12:])
                 nzterm = 4.0 / ((1.0 / scale[c]) * N)
                 # (a slope is the difference of two heights over a vector at least nzterm long: the normal may be off by the heights' error / nzterm)
@@ -114,14 +114,31 @@ for q in range(sequences):
                 oc.set_cascade(c, scale[c], chop[c])      # (updates queued before it were issued under the old wave scale: the model applied them at once)
                 displaced = False
             elif op == "format":
-                half = not half
-                log.append(("format", half))
-                oc.set_spectrum_format(half)
+                # (ABI 7: the fp16 format and the literal mode -- the reference's fp32 arithmetic -- refuse each other with ESTATE instead of one silently winning)
+                if literal and not half:
+                    try:
+                        oc.set_spectrum_format(True)
+                        raise AssertionError((q, "fp16 format accepted in literal mode", log[-12:]))
+                    except capi.OceanError as e:
+                        assert e.code == capi.ESTATE
+                    log.append(("format refused", half))
+                else:
+                    half = not half
+                    log.append(("format", half))
+                    oc.set_spectrum_format(half)
                 displaced = False
             elif op == "literal":
-                literal = not literal
-                log.append(("literal", literal))
-                oc.set_literal_transform(literal)
+                if half and not literal:
+                    try:
+                        oc.set_literal_transform(True)
+                        raise AssertionError((q, "literal mode accepted with the fp16 spectrum", log[-12:]))
+                    except capi.OceanError as e:
+                        assert e.code == capi.ESTATE
+                    log.append(("literal refused", literal))
+                else:
+                    literal = not literal
+                    log.append(("literal", literal))
+                    oc.set_literal_transform(literal)
                 displaced = False
             elif op == "read_state":
                 c = int(rng.integers(0, C))
