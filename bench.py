@@ -455,6 +455,8 @@ def main():
     comm_cus = args.comm_cus if args.comm_cus >= 0 else ((device_cus // 64) * 8 if (gathering and args.gather == "pipelined" and "DATUM_COMM_CUMASK" not in os.environ and "DATUM_COMPUTE_CUMASK" not in os.environ) else 0)
     if not gathering:
         comm_cus = 0
+    # (for the N > 1 diagnostics below) "applied: 32 of 256 compute units" / "refused: <the module's text>" / "off"
+    partition_state = "off" if not comm_cus else None
     if native:
         box = [capi.farm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
@@ -467,6 +469,7 @@ def main():
             except capi.OceanError as e:
                 # (a runtime without CU masks: the farm works without the partition)
                 print(f"bench.py: rank {rank}: datum_ocean_farm_partition({comm_cus}) refused, both streams on the whole device: {e}", file=sys.stderr)
+                partition_state = f"refused ({comm_cus} asked): {e}"
                 comm_cus = 0
             else:
                 stream = torch.cuda.ExternalStream(oc.own_stream(), device=dev)
@@ -479,6 +482,7 @@ def main():
             except Exception as e:
                 # (a runtime without CU masks: both streams on the whole device, as the native path falls back)
                 print(f"bench.py: rank {rank}: no CU-masked stream ({e}); both streams on the whole device", file=sys.stderr)
+                partition_state = f"refused ({comm_cus} asked): {e}"
                 comm_cus = 0
             else:
                 torch.cuda.set_stream(stream)
@@ -486,6 +490,9 @@ def main():
         tg = farm.TileGather(farm.payload_numel(N, C, args.payload), pdtype, dev, world, standin_peers=args.standin_peers,
                              force_collective=args.force_collective, standin_workgroups=args.standin_workgroups, standin_gbps=args.standin_gbps,
                              comm_cus=comm_cus)
+
+    if partition_state is None:
+        partition_state = f"applied: {comm_cus} of {device_cus} compute units for the communication stream"
 
     def step():
         oc.update(DT)
@@ -612,13 +619,19 @@ def main():
                 for _ in range(5):
                     big.update(DT)
                     big.displace()
+                # throughput from ten steps with nothing between the launches; the kernels' durations from ten more with dispatch events
+                # on every launch (a sampled launch costs the loop ~6 us and a step beyond the cache has two to eight launches: timed
+                # together -- as up to this round's first runs -- the events took 10 % off grids_per_s: 65.9 k against 72-78 k)
                 r0, r1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
-                big.profile_begin(10, 1)
                 r0.record(stream)
                 for _ in range(10):
                     big.update(DT)
                     big.displace()
                 r1.record(stream)
+                big.profile_begin(10, 1)
+                for _ in range(10):
+                    big.update(DT)
+                    big.displace()
                 torch.cuda.synchronize(dev)
                 brow_ms, bcol_ms, bn = big.profile_end()
                 g, launches = big.cascade_group()
@@ -632,8 +645,8 @@ def main():
             one_launch = regime_leg(RC)          # every cascade in one launch per pass (the form up to round 5)
             grouped = regime_leg(0)              # the module's cascade groups (what datum_ocean_displace does by default)
             big.set_stream(None)
-        regime = dict(grouped, workload=f"{N}x{N} x {RC} cascades fp32 (1 GB working set: beyond the 256 MiB Infinity Cache), 10 steps after 5, outside the timed region; "
-                                        "rowpass_ms / colpass_ms are sums over a step's launches",
+        regime = dict(grouped, workload=f"{N}x{N} x {RC} cascades fp32 (1 GB working set: beyond the 256 MiB Infinity Cache), outside the timed region: grids_per_s over 10 steps after 5, "
+                                        "the kernels' durations over the next 10 (dispatch events); rowpass_ms / colpass_ms are sums over a step's launches",
                       one_launch_per_pass=one_launch)
 
     # ocean.gen (reported separately, as vertices/s): the 1024 x 1024 projected-grid mesh of the example
@@ -692,7 +705,18 @@ def main():
     compute_ms = ev0.elapsed_time(ev1)     # the compute stream's share (serial: includes the gather it waits for)
     gather_ms = (oc.farm_wait(slot) if native else tg.last_collective_ms(slot)) if gathering else 0.0
 
+    # N > 1: what every rank saw, so that the first run on a real node explains itself: each rank's compute and
+    # collective time, whether its CU partition was applied or refused (and why), its RCCL and the channel settings in its environment
+    per_rank = None
     if multi:
+        mine = {"rank": rank, "device": local_rank, "compute_ms": compute_ms, "gather_ms": gather_ms, "wall_ms": elapsed * 1e3,
+                "without_gather_ms": plain_elapsed * 1e3,
+                "farm_partition": partition_state,
+                "rccl_version": (farm_info["rccl_version"] if native else None),
+                "rccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_")) and k not in ("NCCL_DEBUG_FILE",)}}
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        per_rank = box
         t = torch.tensor([elapsed, compute_ms, gather_ms, plain_elapsed], dtype=torch.float64, device=(dev if args.rendezvous == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, compute_ms, gather_ms, plain_elapsed = (float(v) for v in t.tolist())
@@ -811,6 +835,15 @@ def main():
             "parity": committed_parity(N),
             "compute_ms": compute_ms,
             "gather_ms": gather_ms,
+            # N > 1 only.  bus_GBps: what every rank RECEIVES in one all-gather, (world - 1) payloads, over the slowest rank's collective
+            # time -- the figure DESIGN.md section 6's prediction assumes to be >= 270 GB/s; per_rank: each rank's own view
+            "farm_diagnostics": ({"per_rank": per_rank,
+                                  "gather_ms_max": gather_ms,
+                                  "bytes_received_per_rank": (world - 1) * pbytes if gathering else None,
+                                  "bus_GBps": ((world - 1) * pbytes / (gather_ms * 1e-3) / 1e9 if (gathering and gather_ms > 0 and world > 1) else None),
+                                  "gather_hidden_under_compute": (bool(gather_ms <= compute_ms) if (gathering and args.gather == "pipelined") else None),
+                                  "partition_on_every_rank": (all(str(r["farm_partition"]).startswith("applied") for r in per_rank) if per_rank else None)}
+                                 if multi else None),
             "gen": gen,
             "reference_frame_n64": frame,
             "value_compute_only": grids / (compute_ms * 1e-3) if (compute_ms > 0 and args.gather != "serial") else None,

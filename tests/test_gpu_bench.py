@@ -85,3 +85,9 @@ def test_one_rank_group_with_the_native_gather():
         assert part and part["communication_stream_cus"] == (cus // 64) * 8 and part["communication_stream_cus"] + part["compute_stream_cus"] == cus
     else:
         assert part is None
+    # the N > 1 line explains itself: every rank's own compute / collective time, its partition state, its RCCL
+    d = j["farm_diagnostics"]
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0 and d["per_rank"][0]["gather_ms"] > 0 and d["per_rank"][0]["compute_ms"] > 0
+    assert d["per_rank"][0]["rccl_version"] > 20000 and isinstance(d["per_rank"][0]["rccl_env"], dict)
+    assert d["per_rank"][0]["farm_partition"].startswith("applied" if cus >= 64 else "off")
+    assert d["partition_on_every_rank"] == (cus >= 64) and d["bus_GBps"] is None          # (one rank receives nothing)
