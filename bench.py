@@ -69,8 +69,9 @@ def parse():
     ap.add_argument("--plumbing", action="store_true",
                     help="no GPU: every rank joins a gloo group on the CPU, all-reduces its rank and rank 0 prints one JSON line -- the launcher, "
                          "the environment and the rendezvous of an N-rank run without the ocean (tests/test_bench_launcher.py)")
-    ap.add_argument("--spectrum", choices=("fp32", "fp16"), default="fp32",
-                    help="storage of the work spectrum between the two passes (fp16: BASELINE.json configs[4]; arithmetic stays fp32)")
+    ap.add_argument("--spectrum", choices=("fp32", "fp16", "fp16h0"), default="fp32",
+                    help="storage of the work spectrum between the two passes (fp16: BASELINE.json configs[4]; arithmetic stays fp32); "
+                         "fp16h0: h0 read as halves too (DATUM_OCEAN_SPECTRUM_FP16_H0: SURVEY.md 8d's own byte count for configs[4])")
     ap.add_argument("--cascade-group", type=int, default=0,
                     help="cascades per launch of the two passes (datum_ocean_set_cascade_group); 0 = the module's own choice (sized to the Infinity Cache)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
@@ -339,9 +340,12 @@ def plumbing(rank, world):
     return 0
 
 
+SPECTRUM_WORDS = {"fp32": "fp32", "fp16": "fp32 arithmetic, fp16-stored spectrum", "fp16h0": "fp32 arithmetic, fp16-stored spectrum and h0"}
+
+
 def baseline_config(N, C, world, spectrum):
     """Which BASELINE.json config a run is (or is the per-GPU share of)."""
-    if spectrum == "fp16" and N == 4096:
+    if spectrum in ("fp16", "fp16h0") and N == 4096:
         return "BASELINE.json configs[4]" + ("" if world == 1 else f", one such grid set per GPU x {world}")
     if (N, C) == (2048, 1) and world > 1:
         return f"BASELINE.json configs[3]: 2048x2048 tiles, one per GPU, {world} of its 8" if world != 8 else "BASELINE.json configs[3]: 2048x2048 x 8 tiles farmed across 8 GPUs"
@@ -412,7 +416,7 @@ def main():
 
     # state: this rank's cascades, seeded on the host exactly as seed_ocean does (mt19937(1000 + global index))
     oc = capi.Ocean(N, C, device=local_rank)
-    oc.set_spectrum_format(args.spectrum == "fp16")
+    oc.set_spectrum_format(args.spectrum)
     oc.set_cascade_group(args.cascade_group)
     cascade_group, launches_per_pass = oc.cascade_group()
     for c, g in enumerate(farm.owned_grids(rank, world, C)):
@@ -734,7 +738,8 @@ def main():
         # against the 40 + 56 (24 + 44) algorithmic bytes `achieved` is computed from
         pts = float(N) * N * C
         texel = capi.map_layout(N)[3]
-        moved = ((24.0 if args.spectrum == "fp16" else 32.0) * pts, ((8.0 if args.spectrum == "fp16" else 16.0) + texel) * pts)
+        half = args.spectrum != "fp32"
+        moved = (({"fp32": 32.0, "fp16": 24.0, "fp16h0": 20.0}[args.spectrum]) * pts, ((8.0 if half else 16.0) + texel) * pts)
         # the dominant kernel: strictly the longer of the two (round 5; round 4's tie-break towards the column pass picked the
         # kernel with the larger figure: ADVICE r04)
         dom = ("colpass", col_ms, col_b, moved[1]) if col_ms > row_ms else ("rowpass", row_ms, row_b, moved[0])
@@ -749,8 +754,8 @@ def main():
         phys_bytes = float(traffic) if traffic is not None else dom[3]
         ach = phys_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
         survey_ach = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
-        # h0 8 + phase 4 + work spectrum 16 (8 as halves) + maps: what one step touches
-        working_set = ((20.0 if args.spectrum == "fp16" else 28.0) + texel) * pts
+        # h0 8 (4 as halves) + phase 4 + work spectrum 16 (8 as halves) + maps: what one step touches
+        working_set = (({"fp32": 28.0, "fp16": 20.0, "fp16h0": 16.0}[args.spectrum]) + texel) * pts
         residency = "infinity-cache" if working_set < 256 * 2**20 else "hbm"
 
         line = {
@@ -767,7 +772,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{N}x{N} x {C} cascades per GPU, {'fp32 arithmetic, fp16-stored spectrum' if args.spectrum == 'fp16' else 'fp32'}"
+                "workload": f"{N}x{N} x {C} cascades per GPU, {SPECTRUM_WORDS[args.spectrum]}"
                             f", phase advance + sim + row IFFT + column IFFT + map: {baseline_config(N, C, world, args.spectrum)}",
                 "baseline_config": baseline_config(N, C, world, args.spectrum),
                 "resolution": N,

@@ -118,6 +118,9 @@ SYMBOLS = {
 # installed or copied package has no include/ beside it (tests/test_golden_and_abi.py asserts that the two agree in the source tree).
 ABI_VERSION = 7
 
+# datum_ocean_set_spectrum_format's values (include/datum_ocean_hip.h)
+SPECTRUM_FORMATS = {"fp32": 0, "fp16": 1, "fp16h0": 2}
+
 
 def header_abi_version():
     """DATUM_OCEAN_ABI_VERSION as include/datum_ocean_hip.h states it (source tree only: the tests compare it with ABI_VERSION)."""
@@ -393,8 +396,10 @@ class Ocean:
         return h, hx, hy
 
     def set_spectrum_format(self, fp16):
-        """Work spectrum between the passes as IEEE halves (True) or fp32 (False, default)."""
-        self._check(self.lib.datum_ocean_set_spectrum_format(self.h, 1 if fp16 else 0))
+        """Work spectrum between the passes as IEEE halves (True / "fp16") or fp32 (False / "fp32", default); "fp16h0": the halves and h0
+        read as halves too (DATUM_OCEAN_SPECTRUM_FP16_H0)."""
+        code = SPECTRUM_FORMATS[fp16] if isinstance(fp16, str) else (1 if fp16 else 0)
+        self._check(self.lib.datum_ocean_set_spectrum_format(self.h, code))
 
     def debug_rowpass(self, cascade):
         c, d = (np.empty((self.N, self.N, 2), np.float32) for _ in range(2))

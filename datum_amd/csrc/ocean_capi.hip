@@ -36,7 +36,9 @@ struct datum_ocean_ctx
   float2 *seed = nullptr;             // [cascade][N*N] OceanParams::seed, only when the caller uploads it
   float *phase = nullptr;
   void *spec = nullptr;               // cd[cascades][P], or ch[...] with the fp16 spectrum
-  bool half = false;                  // DATUM_OCEAN_SPECTRUM_FP16
+  bool half = false;                  // DATUM_OCEAN_SPECTRUM_FP16 or _FP16_H0
+  bool h0half = false;                // DATUM_OCEAN_SPECTRUM_FP16_H0: the row pass reads h0 as halves ...
+  unsigned int *h0h = nullptr;        // ... from this copy, [cascades][P] x two halves, rebuilt with the scale when h0 changes (size_spectrum_scale)
   int cascadegroup = 0;               // cascades per launch of the two passes, 0 = sized to the Infinity Cache (cascade_group)
 
   // validation mode (datum_ocean_set_literal_transform): the reference's own radix-2 transforms with its literal twiddle table
@@ -112,6 +114,7 @@ namespace
   {
     StepArgs a;
     a.h0 = ctx->h0;
+    a.h0h = ctx->h0half ? ctx->h0h : nullptr;
     a.phase = ctx->phase;
     a.spec = ctx->spec;
     a.maps = ctx->maps;
@@ -147,7 +150,7 @@ namespace
     if (!maps_stream(ctx->N, ctx->cascades, ctx->half))
       return ctx->cascades;
 
-    g = (int)(CASCADE_GROUP_BYTES / ((double)plane(ctx) * (12.0 + (ctx->half ? 8.0 : 16.0))));
+    g = (int)(CASCADE_GROUP_BYTES / ((double)plane(ctx) * ((ctx->h0half ? 8.0 : 12.0) + (ctx->half ? 8.0 : 16.0))));
     g = g < 1 ? 1 : (g > ctx->cascades ? ctx->cascades : g);
 
     int const groups = (ctx->cascades + g - 1) / g;
@@ -162,6 +165,16 @@ namespace
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N, H16>::LDS);
     if (e != hipSuccess)
       return e;
+
+    if constexpr (H16)
+    {
+      *what = "hipFuncSetAttribute(ocean_rowpass_kernel, the instantiations with h0 as halves, MaxDynamicSharedMemorySize)";
+      e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N, true>::LDS);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N, true>::LDS);
+      if (e != hipSuccess)
+        return e;
+    }
 
     *what = "hipFuncSetAttribute(ocean_rowpass_kernel, the instantiation for phases outside [0, 2 pi), MaxDynamicSharedMemorySize)";
     e = hipFuncSetAttribute(reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowCfg<N, H16>::LDS);
@@ -203,7 +216,7 @@ namespace
     return hipLaunchKernel(kernel, grid, block, args, lds, stream);
   }
 
-  template<int N, bool H16>
+  template<int N, bool H16, bool H0H = false>
   hipError_t launch_rowpass_as(datum_ocean_ctx *ctx, StepArgs &a, hipEvent_t *ev)
   {
     typedef RowCfg<N, H16> C;
@@ -216,7 +229,7 @@ namespace
       wild = wild || ctx->wildphase[c];
 
     void *args[] = { &a };
-    void const *kernel = wild ? reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16, true>) : reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16>);
+    void const *kernel = wild ? reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16, true, H0H>) : reinterpret_cast<void const*>(&ocean_rowpass_kernel<N, H16, false, H0H>);
 
     // work items = groups of row pairs x the cascades of this launch: one workgroup each
     int const items = C::GROUPS * a.cascades;
@@ -227,6 +240,9 @@ namespace
   template<int N>
   hipError_t launch_rowpass(datum_ocean_ctx *ctx, StepArgs &a, hipEvent_t *ev)
   {
+    if (ctx->h0half)
+      return launch_rowpass_as<N, true, true>(ctx, a, ev);
+
     return ctx->half ? launch_rowpass_as<N, true>(ctx, a, ev) : launch_rowpass_as<N, false>(ctx, a, ev);
   }
 
@@ -386,6 +402,26 @@ namespace
 
       ctx->casc[c].specscale = std::ldexp(1.0f, e);
       ctx->casc[c].specinv = std::ldexp(1.0f, -e);
+      ctx->casc[c].rowscale = ctx->casc[c].specscale;
+
+      if (ctx->h0half)
+      {
+        // h0 as halves: the power of two that brings the largest component just under 2^15 (the whole of half's range below it is
+        // h0's: 2^-29 of the largest value is still a normal half, 2^-39 a denormal one); the row pass takes it out again with the
+        // work spectrum's scale in one exact factor
+        int eh = (m > 0) ? (int)std::floor(std::log2(32768.0 / (double)m)) : 0;
+
+        if (m > 0 && std::ldexp((double)m, eh) >= 32768.0)
+          eh -= 1;
+
+        eh = eh > 120 ? 120 : (eh < -120 ? -120 : eh);
+
+        hipLaunchKernelGGL(ocean_h0half_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->h0 + c * P, ctx->h0h + c * P, P, std::ldexp(1.0f, eh));
+        HIPCHECK(ctx, hipGetLastError());
+
+        ctx->casc[c].rowscale = std::ldexp(1.0f, e - eh);
+      }
+
       ctx->scaledirty[c] = false;
     }
 
@@ -599,6 +635,7 @@ int datum_ocean_create(datum_ocean_t *out, int device, int resolution, int casca
     ctx->casc[c].nz = 4 / (ctx->casc[c].scale * resolution);
     ctx->casc[c].specscale = 1.0f;
     ctx->casc[c].specinv = 1.0f;
+    ctx->casc[c].rowscale = 1.0f;
   }
 
   {
@@ -651,6 +688,7 @@ int datum_ocean_destroy(datum_ocean_t ctx)
   (void)hipFree(ctx->phase);
   (void)hipFree(ctx->spec);
   (void)hipFree(ctx->absmax);
+  (void)hipFree(ctx->h0h);
   (void)hipFree(ctx->ownmaps);
   (void)hipFree(ctx->tw);
   (void)hipFree(ctx->omega);
@@ -764,20 +802,27 @@ int datum_ocean_set_spectrum_format(datum_ocean_t ctx, int format)
   if (!ctx)
     return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_set_spectrum_format: null handle");
 
-  if (format != DATUM_OCEAN_SPECTRUM_FP32 && format != DATUM_OCEAN_SPECTRUM_FP16)
+  if (format != DATUM_OCEAN_SPECTRUM_FP32 && format != DATUM_OCEAN_SPECTRUM_FP16 && format != DATUM_OCEAN_SPECTRUM_FP16_H0)
     return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_set_spectrum_format: unknown format");
 
-  if (format == DATUM_OCEAN_SPECTRUM_FP16 && ctx->literal)
+  if (format != DATUM_OCEAN_SPECTRUM_FP32 && ctx->literal)
     return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_set_spectrum_format: the handle is in the literal mode (the reference's fp32 arithmetic); switch it off first");
 
-  ctx->half = (format == DATUM_OCEAN_SPECTRUM_FP16);
+  if (format == DATUM_OCEAN_SPECTRUM_FP16_H0 && !ctx->h0h)
+  {
+    HIPCHECK(ctx, hipSetDevice(ctx->device));
+    HIPCHECK(ctx, hipMalloc(&ctx->h0h, (size_t)ctx->cascades * plane(ctx) * sizeof(unsigned int)));
+  }
+
+  ctx->half = (format != DATUM_OCEAN_SPECTRUM_FP32);
+  ctx->h0half = (format == DATUM_OCEAN_SPECTRUM_FP16_H0);
 
   for(int c = 0; c < ctx->cascades; ++c)
   {
     ctx->scaledirty[c] = ctx->half;
 
     if (!ctx->half)
-      ctx->casc[c].specscale = ctx->casc[c].specinv = 1.0f;
+      ctx->casc[c].specscale = ctx->casc[c].specinv = ctx->casc[c].rowscale = 1.0f;
   }
 
   return DATUM_OCEAN_OK;
@@ -2250,7 +2295,7 @@ int datum_ocean_algorithmic_bytes(datum_ocean_t ctx, double *rowpass_bytes, doub
   // h0 8 + phase in 4 + phase out 4 + spectrum out 24 | spectrum in 24 + two RGBA32F layers 32.
   // The packed step moves 16 instead of 24 spectrum bytes each way and 24-byte texels: 32 + 40 = 72 B/pt of HBM traffic.
   // fp16-stored spectrum: 4 + 4 + 4 + 12 | 12 + 32 = 68 B/pt; this build keeps h0 in fp32 and
-  // moves 8 + 4 + 4 + 8 | 8 + 24 = 56 B/pt.
+  // moves 8 + 4 + 4 + 8 | 8 + 24 = 56 B/pt in the format FP16, and with h0 as halves too (FP16_H0) 4 + 4 + 4 + 8 | 8 + 24 = 52 B/pt.
   if (rowpass_bytes) *rowpass_bytes = (ctx->half ? 24.0 : 40.0) * pts;
   if (colpass_bytes) *colpass_bytes = (ctx->half ? 44.0 : 56.0) * pts;
 

@@ -54,11 +54,13 @@ namespace ocean
     float nz;            // 4 / (scale * N)                        (ocean.map.comp:77)
     float specscale;     // fp16 work spectrum only: power of two the row pass multiplies (C, D) by before rounding to half
     float specinv;       // ... and its reciprocal, folded into the column pass's sign factor (1 for the fp32 spectrum)
+    float rowscale;      // h0 as halves only (DATUM_OCEAN_SPECTRUM_FP16_H0): specscale over the power of two the stored h0 carries (size_spectrum_scale)
   };
 
   struct StepArgs
   {
     float2 const *h0;    // [cascade][N*N]       OceanSet::h0
+    unsigned int const *h0h;   // [cascade][N*N]   the same as two IEEE halves times a power of two per cascade (DATUM_OCEAN_SPECTRUM_FP16_H0 only, else null)
     float *phase;        // [cascade][N*N]       OceanSet::phase
     void *spec;          // [cascade - first][N*N] work spectrum of THIS launch (replaces Spectrum::h, hx, hy), blocked layout: cd, or ch (fp16 variant)
     float4 *maps;        // [cascade][2*N*N]     displacementmap, 2 layers, 24-byte texels in patches (map_compact_a / map_compact_b)
@@ -165,6 +167,11 @@ namespace ocean
   __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
   {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, AUX));
+  }
+
+  __device__ __forceinline__ unsigned int buf_load_u32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+  {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, 0);
   }
 
   template<int AUX = 0>
@@ -749,9 +756,16 @@ namespace ocean
   // One group of row pairs per workgroup.
   // WILD: a phase may lie outside [0, 2 pi) (sincos_phase_pair); its own instantiation rather than a branch in the kernel: the
   // registers of the second path cost the 4096^2 fp16 form 12 more bytes of spill and 6 us (profiles/r04_rowpass_packed.txt)
-  template<int N, bool H16, bool WILD = false>
+  // H0H (with H16 only; DATUM_OCEAN_SPECTRUM_FP16_H0, SURVEY.md 8d's own count for BASELINE configs[4]: "spectrum + intermediates stored fp16"):
+  // h0 is read as two halves per point -- 4 instead of 8 bytes for the row itself and for ocean.sim's mirror row, 32 input registers
+  // fewer in flight at 16 points per thread -- from the copy size_spectrum_scale keeps (h0 times a power of two per cascade that brings
+  // max |h0| just under 2^15).  Everything up to the store is linear in h0, so that power of two is taken out again together with the
+  // work spectrum's own scale: one factor, CascadeConst::rowscale, exact.
+  template<int N, bool H16, bool WILD = false, bool H0H = false>
   __global__ void OCEAN_LDS_UNPAIRED __launch_bounds__((RowCfg<N, H16>::THREADS), (RowCfg<N, H16>::MIN_WAVES)) ocean_rowpass_kernel(StepArgs a)
   {
+    static_assert(H16 || !H0H, "h0 as halves goes with the fp16-stored work spectrum");
+
     typedef RowCfg<N, H16> C;
     typedef Plan<N, C::E> P;
     typedef LineFFT<N, 1, C::E> L;
@@ -795,10 +809,34 @@ namespace ocean
     auto row_of = [&](int item) { int const p = group_of(item) * C::PAIRS + pr; return half ? (p == 0 ? N / 2 : N - p) : p; };
 
     // inputs of ocean.sim: this row of phase and h0, the mirror row (sim.comp:59) backwards, the dispersion of the row
+    typedef typename std::conditional<H0H, unsigned int, float2>::type H0V;      // a point of h0 as it is loaded
+
     struct Inputs
     {
       float ph[E], om[E];
-      float2 hk[E], hm[E];
+      H0V hk[E], hm[E];
+    };
+
+    // The halves are widened once, right behind the loads, by two instructions written out (the high half through SDWA): with the C++
+    // casts hipcc sinks the conversions into the sim loop and the 1024^2 form spills 28 bytes under its 80 registers; widened where
+    // they are used the row pass is 4-10 % slower at every size from 512^2 up (profiles/r06_h0_halves.txt).  Exact: every half is a float.
+    auto height = [](H0V const &v) -> cf
+    {
+      if constexpr (H0H)
+      {
+#if defined(__HIP_DEVICE_COMPILE__)
+        float lo, hi;
+        asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(lo) : "v"(v));
+        asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(hi) : "v"(v));
+        return cf{ lo, hi };
+#else
+        typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+        half2_ const h = __builtin_bit_cast(half2_, v);
+        return cf{ (float)h.x, (float)h.y };
+#endif
+      }
+      else
+        return cf{ v.x, v.y };
     };
 
     auto request = [&](int item, int t, Inputs &in)
@@ -810,7 +848,7 @@ namespace ocean
 
       __amdgpu_buffer_rsrc_t romega = make_rsrc(a.omega + cascade * QUAD, QUAD * sizeof(float));
       __amdgpu_buffer_rsrc_t rphase = make_rsrc(a.phase + cascade * plane, plane * sizeof(float));
-      __amdgpu_buffer_rsrc_t rh0 = make_rsrc(a.h0 + cascade * plane, plane * sizeof(float2));
+      __amdgpu_buffer_rsrc_t rh0 = H0H ? make_rsrc(a.h0h + cascade * plane, plane * sizeof(unsigned int)) : make_rsrc(a.h0 + cascade * plane, plane * sizeof(float2));
 
       int const e0 = y * N + t;
       int const m0 = (N - 1 - y) * N + (N - 1 - t - T * (E - 1));
@@ -819,8 +857,17 @@ namespace ocean
       for(int s = 0; s < E; ++s)
       {
         in.ph[s] = buf_load_f32(rphase, e0 * 4, T * s * 4);
-        in.hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
-        in.hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
+
+        if constexpr (H0H)
+        {
+          in.hk[s] = buf_load_u32(rh0, e0 * 4, T * s * 4);
+          in.hm[s] = buf_load_u32(rh0, m0 * 4, T * (E - 1 - s) * 4);
+        }
+        else
+        {
+          in.hk[s] = buf_load_f32x2(rh0, e0 * 8, T * s * 8);
+          in.hm[s] = buf_load_f32x2(rh0, m0 * 8, T * (E - 1 - s) * 8);
+        }
       }
 
       if (advance)
@@ -875,14 +922,14 @@ namespace ocean
       __amdgpu_buffer_rsrc_t rspec = make_rsrc(static_cast<SV*>(a.spec) + (cascade - a.first) * plane, plane * sizeof(SV));
 
       float ph[E];
-      float2 hk[E], hm[E];
+      cf hk[E], hm[E];
 
       #pragma unroll
       for(int s = 0; s < E; ++s)
       {
         ph[s] = in.ph[s];
-        hk[s] = in.hk[s];
-        hm[s] = in.hm[s];
+        hk[s] = height(in.hk[s]);
+        hm[s] = height(in.hm[s]);
       }
 
       // update_ocean (ocean.cpp:223-233), each pending dt in turn
@@ -930,7 +977,7 @@ namespace ocean
           // sim_height_products with e^{i phase} from the pair
           cf const e = cf{ cs[i], sn[i] };
 
-          h[s + i] = add_conj(cmul(cf{ hk[s + i].x, hk[s + i].y }, e), cmul(cf{ hm[s + i].x, hm[s + i].y }, e));
+          h[s + i] = add_conj(cmul(hk[s + i], e), cmul(hm[s + i], e));
 
           swap_out[t + T * (s + i)] = h[s + i];
         }
@@ -1013,7 +1060,8 @@ namespace ocean
         if constexpr (H16)
         {
           // round to nearest even; the host picks specscale so that no row sum can overflow (ocean_capi: spectrum_scale)
-          half4_ const hv = { (_Float16)(v[0][s].x * cc.specscale), (_Float16)(v[0][s].y * cc.specscale), (_Float16)(v[1][s].x * cc.specscale), (_Float16)(v[1][s].y * cc.specscale) };
+          float const sc = H0H ? cc.rowscale : cc.specscale;
+          half4_ const hv = { (_Float16)(v[0][s].x * sc), (_Float16)(v[0][s].y * sc), (_Float16)(v[1][s].x * sc), (_Float16)(v[1][s].y * sc) };
 
           buf_store_cf_aux<SPEC_STORE_AUX>(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
         }
@@ -1405,6 +1453,20 @@ namespace ocean
 
       c[i] = cf{ v.x, v.y };
       d[i] = cf{ v.z, v.w };
+    }
+  }
+
+  // h0 as two halves per point, times a power of two (DATUM_OCEAN_SPECTRUM_FP16_H0; re-run when h0 changes, like the reduction below)
+  __global__ void ocean_h0half_kernel(float2 const *h0, unsigned int *h0h, size_t count, float scale)
+  {
+    typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+
+    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    {
+      float2 const v = h0[i];
+      half2_ const h = { (_Float16)(v.x * scale), (_Float16)(v.y * scale) };      // round to nearest even
+
+      h0h[i] = __builtin_bit_cast(unsigned int, h);
     }
   }
 

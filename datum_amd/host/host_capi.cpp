@@ -183,7 +183,7 @@ extern "C"
     catch(std::exception const &e) { return caught(e); }
   }
 
-  // initialise_ocean_context + prepare_ocean_context (examples/ocean/ocean.cpp:31,165); flags: 1 = OceanContext::spectrumfp16, 2 = ::literaltransform
+  // initialise_ocean_context + prepare_ocean_context (examples/ocean/ocean.cpp:31,165); flags: 1 = OceanContext::spectrumfp16, 2 = ::literaltransform, 4 = ::heightfp16
   void *datum_host_context_create_ex(int device, int resolution, int flags)
   {
     HostContext *hc = nullptr;
@@ -195,6 +195,7 @@ extern "C"
       hc->context.resolution = resolution;
       hc->context.spectrumfp16 = (flags & 1) != 0;
       hc->context.literaltransform = (flags & 2) != 0;
+      hc->context.heightfp16 = (flags & 4) != 0;
 
       initialise_ocean_context(hc->platform, hc->context, 0);
 

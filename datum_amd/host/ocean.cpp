@@ -739,7 +739,7 @@ bool prepare_ocean_context(DatumPlatform::PlatformInterface &platform, OceanCont
     throw runtime_error(string("HIP ocean module create failed: ") + datum_ocean_last_error(nullptr));
 
   if (context.spectrumfp16)
-    check(context.hip, datum_ocean_set_spectrum_format(context.hip, DATUM_OCEAN_SPECTRUM_FP16), "datum_ocean_set_spectrum_format");
+    check(context.hip, datum_ocean_set_spectrum_format(context.hip, context.heightfp16 ? DATUM_OCEAN_SPECTRUM_FP16_H0 : DATUM_OCEAN_SPECTRUM_FP16), "datum_ocean_set_spectrum_format");
 
   if (context.literaltransform)
     check(context.hip, datum_ocean_set_literal_transform(context.hip, 1), "datum_ocean_set_literal_transform");

@@ -138,6 +138,8 @@ struct OceanContext
   int device = 0;
 
   bool spectrumfp16 = false;              // extension: store the module's work spectrum as halves (set before prepare_ocean_context)
+  bool heightfp16 = false;                // with spectrumfp16: the module reads OceanParams::height as halves too, from a device copy of its own
+                                          // (DATUM_OCEAN_SPECTRUM_FP16_H0; what the caller holds and fetches stays fp32)
   bool literaltransform = false;          // validation: displace through the reference's own radix-2 transforms and literal twiddle table
                                           // (datum_ocean_set_literal_transform; set before prepare_ocean_context) -- for texel-for-texel A/B with the Vulkan build;
                                           // not together with spectrumfp16 (the mode is the reference's fp32 arithmetic: prepare_ocean_context throws)

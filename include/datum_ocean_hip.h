@@ -39,7 +39,9 @@ extern "C" {
  *   3  round 3: ENOTREADY = +1, datum_ocean_map_layout with four arguments, 32-byte texels
  *   4  round 4: ENOTREADY = -5, datum_ocean_map_layout gained texel_bytes, 24-byte texels in bound map buffers, farm entry points
  *   5  round 5: datum_ocean_abi_version, datum_ocean_export_maps, datum_ocean_set_literal_transform
- *   6  round 5: datum_ocean_farm_partition, datum_ocean_own_stream */
+ *   6  round 5: datum_ocean_farm_partition, datum_ocean_own_stream
+ *   7  round 6: datum_ocean_set_cascade_group / datum_ocean_cascade_group (DATUM_OCEAN_SPECTRUM_FP16_H0, a further value of an existing
+ *      argument, came later in the round without a bump) */
 #define DATUM_OCEAN_ABI_VERSION 7
 int datum_ocean_abi_version(void);
 
@@ -119,9 +121,16 @@ int datum_ocean_set_cascade(datum_ocean_t ctx, int cascade, float wavescale, flo
 /* Extension (BASELINE.json configs[4]): how the work spectrum between the two passes is stored.  FP32 (default): 16 B
  * per point.  FP16: 8 B per point, arithmetic stays fp32; the values are scaled by a power of two sized from max |h0|
  * so that no row sum can overflow a half.  Displacement error then ~5e-4 relative to the largest displacement
- * (tests state 2e-3).  Takes effect at the next datum_ocean_displace. */
+ * (tests state 2e-3).  Takes effect at the next datum_ocean_displace.
+ * FP16_H0 (round 6; SURVEY.md 8d's own byte count for that config -- "spectrum + intermediates stored fp16": h0 4 B/pt): FP16, and the
+ * row pass reads h0 as two halves per point as well, from a copy the module keeps beside the fp32 h0 (4 more bytes per point of
+ * device memory; rebuilt on the device whenever h0 changes: upload, rebuild from the seed, resume): h0 times the power of two that
+ * brings its largest component just under 2^15, rounded to nearest even.  What the caller uploads and fetches stays fp32; the phase
+ * state never passes through a half and stays bit-exact.  Same stated tolerance (2e-3 of the largest displacement; measured with
+ * the example's parameters: tests/test_gpu_parity.py). */
 #define DATUM_OCEAN_SPECTRUM_FP32 0
 #define DATUM_OCEAN_SPECTRUM_FP16 1
+#define DATUM_OCEAN_SPECTRUM_FP16_H0 2
 int datum_ocean_set_spectrum_format(datum_ocean_t ctx, int format);
 
 /* VALIDATION MODE (round 5): displace through the reference's own algorithm instead of the fused kernels -- ocean.sim, log2 N

@@ -183,6 +183,38 @@ def test_the_reference_configuration_in_literal_mode_against_the_golden_maps(ora
         assert np.array_equal(p.phase, g["phase_600"])
 
 
+@pytest.mark.parametrize("heightfp16", [False, True])
+def test_the_fp16_formats_through_the_host_api(oracle, heightfp16):
+    # OceanContext::spectrumfp16 (+ ::heightfp16: the module reads OceanParams::height as halves too, DATUM_OCEAN_SPECTRUM_FP16_H0) through
+    # the C++ mirror: displacement within the stated fp16 tolerance of the fp32 context's (RMSE < 2e-3 of the largest |displacement|),
+    # before and after lerp_ocean_waves changed every h0 (the module's half copy has to follow the new h0), the phase state bit for bit the
+    # fp32 context's and the caller's h0 untouched
+    from datum_amd import host_api
+
+    N = 256
+    p = host_api.OceanParams(N, **host_api.EXAMPLE_TUNABLES)
+    p.seed_ocean(1003)
+    with host_api.OceanContext(N, spectrumfp16=True, heightfp16=heightfp16) as half, host_api.OceanContext(N) as full:
+        for leg in range(2):
+            for _ in range(3):
+                p.update_ocean(DT)
+            before = p.height.copy()
+            half.displace_ocean_surface(p)
+            full.displace_ocean_surface(p)
+            m, mf = half.read_displacement(), full.read_displacement()
+            big = float(np.abs(mf[..., :3]).max())
+            e = rmse(m[..., :3], mf[..., :3])
+            assert big > 0.05 and 1e-7 * big < e < 2e-3 * big, (leg, e / big)
+            assert np.array_equal(p.height, before)
+            if leg == 0:
+                p.lerp_ocean_waves(40.0, 0.004, 11.0, (0.6, 0.8), 1.0)
+                assert not np.array_equal(p.height, before)
+        half.fetch_ocean_state(p)
+        ph = p.phase.copy()
+        full.fetch_ocean_state(p)
+        assert np.array_equal(ph, p.phase) and float(np.abs(ph).max()) > 0
+
+
 def test_device_side_spectrum_rebuild(oracle):
     # lerp_ocean_waves' h0 rebuild on the device from the resident seed.
     # Tolerance: expf / division differ from libm by ulps -> 2e-6 relative to the largest |h0| (and exact zeros

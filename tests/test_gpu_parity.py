@@ -843,8 +843,11 @@ def test_export_maps_is_the_reference_image_on_the_device(capi, oracle, torch, N
     assert np.all(want[..., 3] == 0) and float(np.abs(want[0, ..., 2]).max()) > 0
 
 
+@pytest.mark.parametrize("fmt", ["fp16", "fp16h0"])
 @pytest.mark.parametrize("N", [256, 1024])
-def test_fp16_spectrum_against_oracle(capi, oracle, report, N):
+def test_fp16_spectrum_against_oracle(capi, oracle, report, N, fmt):
+    # fmt "fp16h0" (DATUM_OCEAN_SPECTRUM_FP16_H0, SURVEY.md 8d's byte count for configs[4]): h0 is read as halves too -- one more
+    # rounding of 2^-11 per coefficient in front of the sum, same stated tolerance
     # BASELINE.json configs[4]: work spectrum stored as IEEE halves (8 B/pt between the passes), arithmetic fp32.
     # Tolerance re-stated for fp16: each stored value carries a relative error <= 2^-11 (round to nearest; the scale is
     # sized so that nothing overflows), and a displacement is a sum of N of them with random signs, so the error is
@@ -853,7 +856,7 @@ def test_fp16_spectrum_against_oracle(capi, oracle, report, N):
     p = oracle.EXAMPLE
     h0 = make_state(oracle, N, 1000)
     with capi.Ocean(N, 1) as oc:
-        oc.set_spectrum_format(True)
+        oc.set_spectrum_format(fmt)
         oc.set_cascade(0, p["wavescale"], p["choppiness"])
         oc.upload_state(0, h0)
         for _ in range(3):
@@ -861,6 +864,7 @@ def test_fp16_spectrum_against_oracle(capi, oracle, report, N):
             oc.displace()
         got = oc.read_maps(0)
         gphase = oc.read_state(0)
+        assert np.array_equal(oc.read_height(0), h0)      # what the caller uploaded stays fp32
         oc.set_spectrum_format(False)      # back to fp32 on the same handle
         oc.displace()
         exact = oc.read_maps(0)
@@ -872,7 +876,7 @@ def test_fp16_spectrum_against_oracle(capi, oracle, report, N):
     scale = float(np.abs(ref[0][..., :3]).max())
     assert rmse(exact[0][..., :3], ref[0][..., :3]) < 1e-5
     e = rmse(got[0][..., :3], ref[0][..., :3])
-    report(f"fp16-stored spectrum N={N}: disp rmse vs oracle {e:.3e} (= {e / scale:.2e} of largest |disp|; bar 2e-3)")
+    report(f"fp16-stored spectrum ({fmt}) N={N}: disp rmse vs oracle {e:.3e} (= {e / scale:.2e} of largest |disp|; bar 2e-3)")
     assert 1e-7 * scale < e < 2e-3 * scale        # really went through halves, and within the stated tolerance
     assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 1e-2
     assert np.all(got[..., 3] == 0)
@@ -894,22 +898,29 @@ def test_fp16_spectrum_4096(capi, oracle, report):
         oc.set_spectrum_format(True)
         oc.displace()
         got = oc.read_maps(0)
+        oc.set_spectrum_format("fp16h0")      # h0 read as halves too (the same phase: no update pending)
+        oc.displace()
+        goth = oc.read_maps(0)
         gphase = oc.read_state(0)
     phase = np.zeros((N, N), np.float32)
     oracle.update(phase, p["wavescale"], DT, mt=True)
     assert np.array_equal(gphase, phase)
     ref = oracle.displace(h0, phase.copy(), p["wavescale"], p["choppiness"], w=oracle.weights(N, reduced=True), mt=True)
-    assert np.isfinite(got).all()
+    assert np.isfinite(got).all() and np.isfinite(goth).all()
     scale = float(np.abs(ref[0][..., :3]).max())
     e32 = rmse(exact[0][..., :3], ref[0][..., :3])
     e16 = rmse(got[0][..., :3], ref[0][..., :3])
+    e16h = rmse(goth[0][..., :3], ref[0][..., :3])
     n16 = float(np.abs(got[1][..., :3] - ref[1][..., :3]).max())
+    n16h = float(np.abs(goth[1][..., :3] - ref[1][..., :3]).max())
     report(f"fp16-stored spectrum N=4096: disp rmse vs oracle fp16 {e16:.3e} (= {e16 / scale:.2e} of largest |disp| {scale:.3e}; bar 2e-3), "
-           f"fp32 {e32:.3e}; normal max abs err fp16 {n16:.3e}")
+           f"fp16 with h0 as halves {e16h:.3e} (= {e16h / scale:.2e}), fp32 {e32:.3e}; normal max abs err fp16 {n16:.3e}, with h0 as halves {n16h:.3e}")
     assert e32 < 1e-5
     assert 1e-7 * scale < e16 < 2e-3 * scale
-    assert n16 < 2e-2
-    assert np.all(got[..., 3] == 0)
+    assert 1e-7 * scale < e16h < 2e-3 * scale
+    assert n16 < 2e-2 and n16h < 2e-2
+    assert not np.array_equal(got, goth)               # the second format really read other bits
+    assert np.all(got[..., 3] == 0) and np.all(goth[..., 3] == 0)
 
 
 def test_handles_come_and_go(capi, oracle, torch):
@@ -998,7 +1009,7 @@ def test_flat_ocean(capi, N):
                 assert np.abs(m[1][..., 2] - 1).max() < 1e-6
 
 
-@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("half", [False, True, "fp16h0"])
 @pytest.mark.parametrize("case", range(6))
 def test_random_parameters(capi, oracle, case, half):
     # three cascades with random wave scales (1 .. 2000), wave amplitudes over four decades, choppiness (0 .. 2), and random
@@ -1047,7 +1058,7 @@ def test_random_parameters(capi, oracle, case, half):
                     assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 2e-5
 
 
-@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("half", [False, True, "fp16h0"])
 def test_power_of_two_amplitudes(capi, oracle, half):
     # The displacement is linear in h0 and a power of two commutes with every rounding, so h0 * 2^k must give the displacement
     # * 2^k BIT FOR BIT -- in fp32, and through the fp16-stored spectrum as well, whose scale exponent follows max |h0|
@@ -1085,6 +1096,9 @@ def test_fp16_spectrum_2048(capi, oracle, report):
             oc.update(DT)
             oc.displace()
         got = oc.read_maps(0)
+        oc.set_spectrum_format("fp16h0")
+        oc.displace()
+        goth = oc.read_maps(0)
         gphase = oc.read_state(0)
     phase = np.zeros((N, N), np.float32)
     for _ in range(2):
@@ -1092,11 +1106,45 @@ def test_fp16_spectrum_2048(capi, oracle, report):
     assert np.array_equal(gphase, phase)
     ref = oracle.displace(h0, phase.copy(), p["wavescale"], p["choppiness"], w=oracle.weights(N, reduced=True), mt=True)
     scale = float(np.abs(ref[0][..., :3]).max())
-    e = rmse(got[0][..., :3], ref[0][..., :3])
-    report(f"fp16-stored spectrum N=2048: disp rmse vs oracle {e:.3e} (= {e / scale:.2e} of largest |disp|; bar 2e-3)")
-    assert 1e-7 * scale < e < 2e-3 * scale
-    assert np.abs(got[1][..., :3] - ref[1][..., :3]).max() < 2e-2
-    assert np.all(got[..., 3] == 0)
+    for what, g in (("", got), (" with h0 as halves", goth)):
+        e = rmse(g[0][..., :3], ref[0][..., :3])
+        report(f"fp16-stored spectrum{what} N=2048: disp rmse vs oracle {e:.3e} (= {e / scale:.2e} of largest |disp|; bar 2e-3)")
+        assert 1e-7 * scale < e < 2e-3 * scale
+        assert np.abs(g[1][..., :3] - ref[1][..., :3]).max() < 2e-2
+        assert np.all(g[..., 3] == 0)
+
+
+@pytest.mark.parametrize("N", [64, 256, 512, 1024, 2048])
+def test_h0_as_halves_is_the_fp16_format_on_an_h0_that_halves_hold(capi, oracle, N):
+    # An exact pin of the FP16_H0 row pass (every row-pass form: 4 / 8 / 16 points per thread, the sequential form, the banded layout):
+    # an h0 whose every component IS a half times the power of two the module picks (the largest component just under 2^15) loses
+    # nothing in the module's copy, and a power of two commutes with every rounding in between -- so the format that reads h0 as
+    # halves must give the maps of the plain fp16 format BIT FOR BIT, update after update, and after h0 is uploaded again
+    p = oracle.EXAMPLE
+    for seed, k in ((1000, 0), (1001, -17)):
+        h0 = np.ldexp(make_state(oracle, N, seed), k).astype(np.float32)
+        m = float(np.abs(h0).max())
+        eh = int(np.floor(np.log2(32768.0 / m)))
+        if np.ldexp(m, eh) >= 32768.0:
+            eh -= 1
+        held = np.ldexp(np.ldexp(h0, eh).astype(np.float16).astype(np.float32), -eh).astype(np.float32)
+        assert float(np.abs(held).max()) == float(np.abs(np.ldexp(np.ldexp(held, eh).astype(np.float16).astype(np.float32), -eh)).max())
+        assert rmse(held, h0) > 0                                   # (the rounding did something)
+        outs = {}
+        with capi.Ocean(N, 1) as oc:
+            oc.set_cascade(0, p["wavescale"], p["choppiness"])
+            for fmt in ("fp16", "fp16h0"):
+                oc.set_spectrum_format(fmt)
+                oc.upload_state(0, held)                            # (the phase starts from zero again)
+                frames = []
+                for _ in range(3):
+                    oc.update(DT)
+                    oc.displace()
+                    frames.append(oc.read_maps(0))
+                outs[fmt] = frames
+        for a, b in zip(outs["fp16"], outs["fp16h0"]):
+            assert float(np.abs(a[0][..., 2]).max()) > 0
+            assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("N,C", [(64, 2), (256, 3), (2048, 1)])
