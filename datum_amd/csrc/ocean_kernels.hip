@@ -89,6 +89,11 @@ namespace ocean
 
   constexpr int SBR = 8, SBC = 8;
 
+  // columns per block, by the stored value's size.  The 8-byte values of the fp16-stored spectrum keep 8 columns (64-byte block rows): with 16 -- whole
+  // lines per row-pass store -- the row pass gains 6-14 us at 4096^2 and 2048^2 x 4 and the column pass, whose narrow tiles then take 16 bytes of
+  // every line they touch, loses as much or more (profiles/r06_spectrum_blocks.txt: 4096^2 with h0 as halves 5.2 -> 5.1 k grids/s)
+  __host__ __device__ __forceinline__ constexpr int spec_block_cols(bool half) { return half ? 8 : SBC; }
+
   // Bands (large grids): the columns one XCD's column-pass workgroups work on at the same time are made contiguous in
   // memory -- [x / B][rows][x % B] -- for the work spectrum and for the maps alike, so that what is read and written
   // concurrently is a dense region instead of 2 KB pieces of rows 128 KB apart (4096^2).  B = band_cols(N), 0 = whole rows.
@@ -98,17 +103,18 @@ namespace ocean
   __host__ __device__ __forceinline__ constexpr int band_cols(int N) { return (N >= 2048) ? 128 : N; }
 
   // element index of grid point (y, x) in the blocked work spectrum: per band, blocks of SBR rows x SBC columns, row-major inside
-  __host__ __device__ __forceinline__ constexpr size_t blocked_at(int N, int y, int x)
+  __host__ __device__ __forceinline__ constexpr size_t blocked_at(int N, int y, int x, bool half = false)
   {
     int const B = band_cols(N);
+    int const BC = spec_block_cols(half);
 
-    return (size_t)(x / B) * N * B + ((size_t)(y / SBR) * (B / SBC) + (x % B) / SBC) * (SBR * SBC) + (y % SBR) * SBC + (x % SBC);
+    return (size_t)(x / B) * N * B + ((size_t)(y / SBR) * (B / BC) + (x % B) / BC) * (SBR * BC) + (y % SBR) * BC + (x % BC);
   }
 
-  template<int N>
+  template<int N, bool H16 = false>
   __host__ __device__ __forceinline__ constexpr size_t blocked(int y, int x)
   {
-    return blocked_at(N, y, x);
+    return blocked_at(N, y, x, H16);
   }
 
   // Displacement map layout (private to this module: in the reference the map is a VK_IMAGE_TILING_OPTIMAL 2-layer image whose
@@ -796,9 +802,9 @@ namespace ocean
 
     size_t const plane = (size_t)N * N;
 
-    constexpr int DBO = (int)(blocked<N>(0, T) - blocked<N>(0, 0));
+    constexpr int DBO = (int)(blocked<N, H16>(0, T) - blocked<N, H16>(0, 0));
 
-    static_assert(T % SBC == 0, "slots must be whole blocks apart");
+    static_assert(T % spec_block_cols(H16) == 0, "slots must be whole blocks apart");
     static_assert(C::LINE >= N + 2 && C::LINE % 2 == 0, "the Hermitian swap fits the line; lines stay 16-byte aligned");
 
     typedef typename SpecValue<H16>::type SV;
@@ -1063,7 +1069,7 @@ namespace ocean
           float const sc = H0H ? cc.rowscale : cc.specscale;
           half4_ const hv = { (_Float16)(v[0][s].x * sc), (_Float16)(v[0][s].y * sc), (_Float16)(v[1][s].x * sc), (_Float16)(v[1][s].y * sc) };
 
-          buf_store_cf_aux<SPEC_STORE_AUX>(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N>(y, t) * 8, DBO * s * 8);
+          buf_store_cf_aux<SPEC_STORE_AUX>(__builtin_bit_cast(cf, hv), rspec, (int)blocked<N, true>(y, t) * 8, DBO * s * 8);
         }
         else
         {
@@ -1183,7 +1189,7 @@ namespace ocean
     int const cp_ = threadIdx.x % W;
     int const t_ = threadIdx.x / W;
 
-    constexpr int DBI = (int)(blocked<N>(T, 0) - blocked<N>(0, 0));      // blocked spectrum, slot to slot (elements)
+    constexpr int DBI = (int)(blocked<N, H16>(T, 0) - blocked<N, H16>(0, 0));      // blocked spectrum, slot to slot (elements)
 
     static_assert(T % SBR == 0, "slots must be whole blocks apart");
 
@@ -1208,7 +1214,7 @@ namespace ocean
       for(int s = 0; s < E; ++s)
       {
         if constexpr (H16)
-          q[s] = buf_load_cf(rspec, (int)blocked<N>(t, x) * 8, DBI * s * 8);
+          q[s] = buf_load_cf(rspec, (int)blocked<N, true>(t, x) * 8, DBI * s * 8);
         else
           q[s] = buf_load_f32x4_aux<0>(rspec, (int)blocked<N>(t, x) * 16, DBI * s * 16);
       }
@@ -1439,7 +1445,7 @@ namespace ocean
     {
       int y = (int)(i / N), x = (int)(i % N);
 
-      size_t const at = blocked_at(N, y, x);
+      size_t const at = blocked_at(N, y, x, H16);
 
       float4 v;
 

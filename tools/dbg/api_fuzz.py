@@ -53,6 +53,7 @@ for q in range(sequences):
     chop = [float(rng.uniform(0.0, 2.0)) for _ in range(C)]
     h0, phase, seeds = [], [], []
     half = False
+    fmt = "fp32"
     literal = False
     parked = []           # (device tensor, flags, h0, phase)
     displaced = False     # the maps are those of the model's state
@@ -117,15 +118,17 @@ for q in range(sequences):
                 # (ABI 7: the fp16 format and the literal mode -- the reference's fp32 arithmetic -- refuse each other with ESTATE instead of one silently winning)
                 if literal and not half:
                     try:
-                        oc.set_spectrum_format(True)
+                        oc.set_spectrum_format(str(rng.choice(["fp16", "fp16h0"])))
                         raise AssertionError((q, "fp16 format accepted in literal mode", log[-12:]))
                     except capi.OceanError as e:
                         assert e.code == capi.ESTATE
                     log.append(("format refused", half))
                 else:
-                    half = not half
-                    log.append(("format", half))
-                    oc.set_spectrum_format(half)
+                    # (fp32 <-> one of the two fp16 formats, or from one fp16 format to the other: h0 read as halves too, DATUM_OCEAN_SPECTRUM_FP16_H0)
+                    fmt = str(rng.choice([f for f in ("fp32", "fp16", "fp16h0") if f != fmt]))
+                    half = fmt != "fp32"
+                    log.append(("format", fmt))
+                    oc.set_spectrum_format(fmt)
                 displaced = False
             elif op == "literal":
                 if half and not literal:

@@ -33,7 +33,8 @@ worst = dict(maps=0.0, normal=0.0, pos=0.0, frame=0.0)
 for k in range(cases):
     N = int(rng.choice([64, 128, 256, 512, 1024], p=[0.25, 0.25, 0.25, 0.15, 0.10])) if not os.environ.get("FUZZ_SIZES") else int(rng.choice([int(v) for v in os.environ["FUZZ_SIZES"].split(",")]))
     C = int(rng.integers(1, 4)) if N <= 1024 else int(rng.integers(1, 3))
-    half = bool(rng.random() < 0.2)
+    half = bool(rng.random() < 0.3)
+    h0half = half and bool(rng.random() < 0.5)          # DATUM_OCEAN_SPECTRUM_FP16_H0: h0 read as halves too
     scales = np.exp(rng.uniform(np.log(2.0), np.log(600.0), C)).astype(np.float32)
     chops = rng.uniform(0.0, 2.0, C).astype(np.float32)
     amps = (0.0025 * 10.0 ** rng.uniform(-1.5, 1.5, C)).astype(np.float32)
@@ -41,7 +42,7 @@ for k in range(cases):
     phases = [np.zeros((N, N), np.float32) for _ in range(C)]
     w = oracle.weights(N, reduced=True)
     with capi.Ocean(N, C) as oc:
-        oc.set_spectrum_format(half)
+        oc.set_spectrum_format("fp16h0" if h0half else half)
         for c in range(C):
             oc.set_cascade(c, float(scales[c]), float(chops[c]))
             oc.upload_state(c, states[c])
@@ -90,5 +91,5 @@ for k in range(cases):
         assert np.isfinite(got).all() and np.all(got[..., 11] == -1)
         assert pos < 2e-4 and tex < 2e-4 and frame < 2e-4, (k, "gen", case, N, sx, sy, pos, tex, frame)
         worst["pos"], worst["frame"] = max(worst["pos"], pos), max(worst["frame"], frame)
-    print(f"case {k:3d}: N={N:4d} x {C} {'fp16' if half else 'fp32'} scales {[round(float(x), 1) for x in scales]}  gen {case} cascade {c} mesh {sx}x{sy}: ok", flush=True)
+    print(f"case {k:3d}: N={N:4d} x {C} {('fp16h0' if h0half else 'fp16') if half else 'fp32'} scales {[round(float(x), 1) for x in scales]}  gen {case} cascade {c} mesh {sx}x{sy}: ok", flush=True)
 print(f"{cases} cases ok; worst fp32 displacement rmse / max {worst['maps']:.2e}, normal max abs {worst['normal']:.2e}, vertex position {worst['pos']:.2e}, frame {worst['frame']:.2e}")
