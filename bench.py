@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--plumbing", action="store_true",
                     help="no GPU: every rank joins a gloo group on the CPU, all-reduces its rank and rank 0 prints one JSON line -- the launcher, "
                          "the environment and the rendezvous of an N-rank run without the ocean (tests/test_bench_launcher.py)")
+    ap.add_argument("--map-stores", choices=("auto", "written through", "streamed"), default="auto",
+                    help="datum_ocean_set_map_store_policy: how the column pass stores the maps.  auto (default): the module's rule -- written through while the "
+                         "handle's working set is resident in the Infinity Cache and no multi-rank farm is initialised, streamed otherwise; with "
+                         "--standin-peers (the collective's footprint without a farm) auto means streamed, as the module would choose on a real farm")
     ap.add_argument("--spectrum", choices=("fp32", "fp16", "fp16h0"), default="fp32",
                     help="storage of the work spectrum between the two passes (fp16: BASELINE.json configs[4]; arithmetic stays fp32); "
                          "fp16h0: h0 read as halves too (DATUM_OCEAN_SPECTRUM_FP16_H0: SURVEY.md 8d's own byte count for configs[4])")
@@ -498,6 +502,15 @@ def main():
     if partition_state is None:
         partition_state = f"applied: {comm_cus} of {device_cus} compute units for the communication stream"
 
+    # the maps' store policy: the module's own rule covers a real farm (streamed while a communicator of several ranks exists); the one-GPU
+    # stand-in has the collective's cache footprint without a communicator, so it asks for what the module would choose there
+    if args.map_stores != "auto":
+        oc.set_map_store_policy(args.map_stores)
+    elif args.standin_peers > 0:
+        oc.set_map_store_policy("streamed")
+    map_policy, maps_streamed = oc.map_store_policy()
+    cascade_group, launches_per_pass = oc.cascade_group()
+
     def step():
         oc.update(DT)
         oc.displace()
@@ -778,6 +791,7 @@ def main():
                 "resolution": N,
                 "cascades_per_gpu": C,
                 "cascades_per_launch": cascade_group,
+                "map_stores": ("streamed (nt)" if maps_streamed else "written through") + f" [policy: {map_policy}]",
                 "launches_per_pass_and_step": launches_per_pass,
                 "grids_per_step": C * world,
                 "gather": ((f"{args.gather}: one all-gather of the {args.payload} payload every {every} step(s), {gathers} inside the timed region"

@@ -58,6 +58,8 @@ SYMBOLS = {
     "datum_ocean_map_layout": (I, [I, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(I)]),
     "datum_ocean_set_cascade": (I, [P, I, F, F]),
     "datum_ocean_set_spectrum_format": (I, [P, I]),
+    "datum_ocean_set_map_store_policy": (I, [P, I]),
+    "datum_ocean_map_store_policy": (I, [P, ctypes.POINTER(I), ctypes.POINTER(I)]),
     "datum_ocean_upload_state": (I, [P, I, P, P]),
     "datum_ocean_read_state": (I, [P, I, P]),
     "datum_ocean_state_bytes": (ctypes.c_size_t, [I]),
@@ -116,10 +118,13 @@ SYMBOLS = {
 
 # DATUM_OCEAN_ABI_VERSION of include/datum_ocean_hip.h as SYMBOLS above was written against it.  A constant, not a read of the header: an
 # installed or copied package has no include/ beside it (tests/test_golden_and_abi.py asserts that the two agree in the source tree).
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # datum_ocean_set_spectrum_format's values (include/datum_ocean_hip.h)
 SPECTRUM_FORMATS = {"fp32": 0, "fp16": 1, "fp16h0": 2}
+
+# datum_ocean_set_map_store_policy's values
+MAP_STORE_POLICIES = {"auto": 0, "written through": 1, "streamed": 2}
 
 
 def header_abi_version():
@@ -433,6 +438,16 @@ class Ocean:
         g, n = I(), I()
         self._check(self.lib.datum_ocean_cascade_group(self.h, ctypes.byref(g), ctypes.byref(n)))
         return g.value, n.value
+
+    def set_map_store_policy(self, policy):
+        """how the column pass stores the maps: "auto" (default), "written through", "streamed" (datum_ocean_set_map_store_policy)"""
+        self._check(self.lib.datum_ocean_set_map_store_policy(self.h, MAP_STORE_POLICIES[policy] if isinstance(policy, str) else int(policy)))
+
+    def map_store_policy(self):
+        """(the policy set, whether the next displace streams the maps)"""
+        p, s = I(), I()
+        self._check(self.lib.datum_ocean_map_store_policy(self.h, ctypes.byref(p), ctypes.byref(s)))
+        return {v: k for k, v in MAP_STORE_POLICIES.items()}[p.value], bool(s.value)
 
     def export_maps(self, cascade, device_ptr, nbytes):
         """the cascade's maps as the reference's [layer][y][x][4] RGBA32F image, into DEVICE memory (datum_ocean_export_maps)"""

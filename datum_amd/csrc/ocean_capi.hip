@@ -40,6 +40,7 @@ struct datum_ocean_ctx
   bool h0half = false;                // DATUM_OCEAN_SPECTRUM_FP16_H0: the row pass reads h0 as halves ...
   unsigned int *h0h = nullptr;        // ... from this copy, [cascades][P] x two halves, rebuilt with the scale when h0 changes (size_spectrum_scale)
   int cascadegroup = 0;               // cascades per launch of the two passes, 0 = sized to the Infinity Cache (cascade_group)
+  int mappolicy = DATUM_OCEAN_MAPS_AUTO;   // datum_ocean_set_map_store_policy
 
   // validation mode (datum_ocean_set_literal_transform): the reference's own radix-2 transforms with its literal twiddle table
   bool literal = false;
@@ -140,6 +141,11 @@ namespace
   // against 78.3 k as 2 x 4; 2048^2 x 4 as 2 x 2 18.2 k against 16.0 k in one launch and 17.2 k as 4 x 1.
   constexpr double CASCADE_GROUP_BYTES = 240.0e6;
 
+  // The maps streamed past the Infinity Cache instead of written through (ocean_kernels.hip: MAP_STORE_AUX_STREAM; 1024^2 and 2048^2 have both forms):
+  // where the handle's own working set is beyond the cache, and -- round 6, profiles/r06_farm_standin.txt -- while a farm of several ranks is
+  // initialised: the collective's gathered buffer competes for the same cache, and the step loses less under it with the maps out of the way.
+  bool handle_streams_maps(datum_ocean_ctx const *ctx);
+
   int cascade_group(datum_ocean_ctx const *ctx)
   {
     int g = ctx->cascadegroup;
@@ -147,7 +153,7 @@ namespace
     if (g > 0)
       return g > ctx->cascades ? ctx->cascades : g;
 
-    if (!maps_stream(ctx->N, ctx->cascades, ctx->half))
+    if (!handle_streams_maps(ctx) || !maps_stream(ctx->N, ctx->cascades, ctx->half))
       return ctx->cascades;
 
     g = (int)(CASCADE_GROUP_BYTES / ((double)plane(ctx) * ((ctx->h0half ? 8.0 : 12.0) + (ctx->half ? 8.0 : 16.0))));
@@ -255,7 +261,7 @@ namespace
     // the maps streamed instead of written through where the HANDLE's working set is beyond the Infinity Cache (whatever this launch's share of it)
     if constexpr (col_has_stream_variant<N>())
     {
-      if (col_streams_maps<N>(ctx->cascades, ctx->half))
+      if (handle_streams_maps(ctx))
         kernel = ctx->half ? colpass_entry<N, true, true>() : colpass_entry<N, false, true>();
     }
 
@@ -1813,6 +1819,50 @@ int datum_ocean_cascade_group(datum_ocean_t ctx, int *cascades_per_launch, int *
 
   if (cascades_per_launch) *cascades_per_launch = group;
   if (launches_per_pass) *launches_per_pass = (ctx->cascades + group - 1) / group;
+
+  return DATUM_OCEAN_OK;
+}
+
+namespace
+{
+  bool handle_streams_maps(datum_ocean_ctx const *ctx)
+  {
+    if (ctx->N >= 4096)
+      return true;
+
+    if (ctx->N < 1024)
+      return false;
+
+    if (ctx->mappolicy != DATUM_OCEAN_MAPS_AUTO)
+      return ctx->mappolicy == DATUM_OCEAN_MAPS_STREAMED;
+
+    return maps_stream(ctx->N, ctx->cascades, ctx->half) || (ctx->farm && ctx->farm->world > 1);
+  }
+}
+
+int datum_ocean_set_map_store_policy(datum_ocean_t ctx, int policy)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_set_map_store_policy: null handle");
+
+  if (policy != DATUM_OCEAN_MAPS_AUTO && policy != DATUM_OCEAN_MAPS_WRITTEN_THROUGH && policy != DATUM_OCEAN_MAPS_STREAMED)
+    return fail(ctx, DATUM_OCEAN_EINVAL, "datum_ocean_set_map_store_policy: unknown policy");
+
+  if (ctx->profiling)
+    return fail(ctx, DATUM_OCEAN_ESTATE, "datum_ocean_set_map_store_policy: a profile is open (the policy can change the cascade groups its samples are per)");
+
+  ctx->mappolicy = policy;
+
+  return DATUM_OCEAN_OK;
+}
+
+int datum_ocean_map_store_policy(datum_ocean_t ctx, int *policy, int *streamed)
+{
+  if (!ctx)
+    return fail(nullptr, DATUM_OCEAN_EINVAL, "datum_ocean_map_store_policy: null handle");
+
+  if (policy) *policy = ctx->mappolicy;
+  if (streamed) *streamed = handle_streams_maps(ctx) ? 1 : 0;
 
   return DATUM_OCEAN_OK;
 }

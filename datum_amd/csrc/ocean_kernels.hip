@@ -1155,11 +1155,6 @@ namespace ocean
     return N >= 4096 || (N >= 1024 && (double)cascades * N * N * (half ? 44.0 : 52.0) > MAPS_RESIDENT_BYTES);
   }
 
-  template<int N> inline bool col_streams_maps(int cascades, bool half)
-  {
-    return col_has_stream_variant<N>() && maps_stream(N, cascades, half);
-  }
-
   template<int N, bool H16, bool STREAM>
   __device__ __forceinline__ void colpass_body(StepArgs const &a)
   {

@@ -41,8 +41,9 @@ extern "C" {
  *   5  round 5: datum_ocean_abi_version, datum_ocean_export_maps, datum_ocean_set_literal_transform
  *   6  round 5: datum_ocean_farm_partition, datum_ocean_own_stream
  *   7  round 6: datum_ocean_set_cascade_group / datum_ocean_cascade_group (DATUM_OCEAN_SPECTRUM_FP16_H0, a further value of an existing
- *      argument, came later in the round without a bump) */
-#define DATUM_OCEAN_ABI_VERSION 7
+ *      argument, came later in the round without a bump)
+ *   8  round 6: datum_ocean_set_map_store_policy / datum_ocean_map_store_policy */
+#define DATUM_OCEAN_ABI_VERSION 8
 int datum_ocean_abi_version(void);
 
 enum
@@ -152,6 +153,20 @@ int datum_ocean_set_literal_transform(datum_ocean_t ctx, int on);   /* DATUM_OCE
  * displace call. */
 int datum_ocean_set_cascade_group(datum_ocean_t ctx, int cascades_per_launch);
 int datum_ocean_cascade_group(datum_ocean_t ctx, int *cascades_per_launch, int *launches_per_pass);
+
+/* How the column pass stores the maps (ABI 8): written through (sc0 sc1: the lines stay in the Infinity Cache for ocean.gen and the next
+ * step) or streamed (nt: past the cache).  AUTO (default): written through while the handle's working set is resident in the cache AND no
+ * multi-rank farm is initialised; streamed otherwise -- a collective's gathered buffer (7 peers' payloads at 8 ranks: 352 MB per batch at
+ * 1024^2 x 4) competes for the same cache, and with the maps kept out of it the step loses less under the collective (one-GPU stand-in,
+ * profiles/r06_farm_standin.txt: 58.5-61.7 k -> 63.2-64.1 k grids/s at 1024^2 x 4, 13.9-14.1 k -> 14.7-15.4 k at 2048^2 x 1; without a
+ * collective in flight streaming costs 2-4 % there).  The explicit values override that.  Grids below 1024^2 are always written through
+ * and 4096^2 always streams (there is one form of their kernels).  Results do not depend on the policy.  The getter reports the policy
+ * set and whether the next displace will stream. */
+#define DATUM_OCEAN_MAPS_AUTO 0
+#define DATUM_OCEAN_MAPS_WRITTEN_THROUGH 1
+#define DATUM_OCEAN_MAPS_STREAMED 2
+int datum_ocean_set_map_store_policy(datum_ocean_t ctx, int policy);
+int datum_ocean_map_store_policy(datum_ocean_t ctx, int *policy, int *streamed);
 
 int datum_ocean_upload_state(datum_ocean_t ctx, int cascade, float const *h0, float const *phase);
 int datum_ocean_read_state(datum_ocean_t ctx, int cascade, float *phase);

@@ -1346,6 +1346,53 @@ def test_native_farm_on_partitioned_compute_units(capi, oracle, torch):
             assert torch.equal(x.cpu(), y.cpu()), (pattern, b)
 
 
+@pytest.mark.parametrize("N,C,fmt", [(512, 2, "fp32"), (1024, 4, "fp32"), (1024, 7, "fp32"), (1024, 4, "fp16h0"), (2048, 1, "fp32"), (4096, 1, "fp16")])
+def test_map_store_policies_do_not_change_the_result(capi, oracle, N, C, fmt):
+    # datum_ocean_set_map_store_policy (ABI 8): the maps written through or streamed past the Infinity Cache -- the same bits either way;
+    # AUTO = written through while the handle's working set fits the cache (300 MB) and no multi-rank farm exists; below 1024^2 there is
+    # only the written-through form, at 4096^2 only the streamed one; a changed policy may change the cascade groups (refused while profiling)
+    p = oracle.EXAMPLE
+    states = [make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c % 4]) for c in range(min(C, 2))]
+    out = {}
+    with capi.Ocean(N, C) as oc:
+        oc.set_spectrum_format(fmt)
+        for c in range(C):
+            oc.set_cascade(c, oracle.CASCADE_WAVESCALES[c % 4], p["choppiness"])
+        assert oc.map_store_policy()[0] == "auto"
+        big = N >= 1024 and C * N * N * (52 if fmt == "fp32" else 44) > 300.0e6
+        for policy in ("auto", "written through", "streamed"):
+            oc.set_map_store_policy(policy)
+            want = {"auto": big, "written through": False, "streamed": True}[policy]
+            want = True if N >= 4096 else (False if N < 1024 else want)
+            assert oc.map_store_policy() == (policy, want)
+            g, launches = oc.cascade_group()
+            assert launches == -(-C // g) and (launches == 1 or (want and big))      # (groups only where the maps are streamed beyond the cache)
+            for c in range(C):
+                oc.upload_state(c, states[c % len(states)])      # (the phase starts from zero again)
+            for _ in range(2):
+                oc.update(DT)
+                oc.displace()
+            out[policy] = [oc.read_maps(c) for c in range(C)]
+        oc.profile_begin(1, 1)
+        with pytest.raises(capi.OceanError) as e:
+            oc.set_map_store_policy("auto")
+        assert e.value.code == capi.ESTATE
+        oc.displace()
+        oc.profile_end()
+        with pytest.raises(capi.OceanError) as e:
+            oc.set_map_store_policy(3)
+        assert e.value.code == capi.EINVAL
+        # a ONE-rank communicator gathers nothing from anybody: the auto rule stays with the handle's own working set
+        oc.set_map_store_policy("auto")
+        oc.farm_init(capi.farm_unique_id(), 0, 1, 1, slots=2)
+        assert oc.map_store_policy() == ("auto", True if N >= 4096 else (big if N >= 1024 else False))
+        oc.farm_shutdown()
+    for c in range(C):
+        assert float(np.abs(out["auto"][c][0][..., 2]).max()) > 0
+        assert np.array_equal(out["auto"][c], out["written through"][c]), c
+        assert np.array_equal(out["auto"][c], out["streamed"][c]), c
+
+
 @pytest.mark.parametrize("N,C,half", [(256, 5, False), (1024, 12, False), (1024, 6, True), (2048, 3, False)])
 def test_cascade_groups_do_not_change_the_result(capi, oracle, N, C, half):
     # datum_ocean_displace launches the two passes per GROUP of cascades (row(g), column(g), row(g + 1), ...: the exchange spectrum of a
