@@ -324,6 +324,26 @@ def launch_ranks(args):
     return 0
 
 
+def rank_report(rank, device, compute_ms, gather_ms, wall_ms, without_gather_ms, partition_state, rccl_version):
+    """What one rank saw (N > 1): gathered from every rank into `farm_diagnostics.per_rank` so that the first run on a real node explains itself"""
+    return {"rank": rank, "device": device, "compute_ms": compute_ms, "gather_ms": gather_ms, "wall_ms": wall_ms, "without_gather_ms": without_gather_ms,
+            "farm_partition": partition_state, "rccl_version": rccl_version,
+            "rccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_")) and k not in ("NCCL_DEBUG_FILE",)}}
+
+
+def farm_diagnostics(per_rank, world, pbytes, gather_ms, compute_ms, gathering, pipelined):
+    """bus_GBps: what every rank RECEIVES in one all-gather, (world - 1) payloads, over the slowest rank's collective time -- the figure DESIGN.md
+    section 7's prediction assumes to be >= 270 GB/s; per_rank: each rank's own view; slowest_rank: whose compute the max-over-ranks timing is"""
+    return {"per_rank": per_rank,
+            "gather_ms_max": gather_ms,
+            "bytes_received_per_rank": (world - 1) * pbytes if gathering else None,
+            "bus_GBps": ((world - 1) * pbytes / (gather_ms * 1e-3) / 1e9 if (gathering and gather_ms > 0 and world > 1) else None),
+            "gather_hidden_under_compute": (bool(gather_ms <= compute_ms) if (gathering and pipelined) else None),
+            "slowest_rank": (max(per_rank, key=lambda r: r["compute_ms"])["rank"] if per_rank else None),
+            "compute_ms_spread": ([min(r["compute_ms"] for r in per_rank), max(r["compute_ms"] for r in per_rank)] if per_rank else None),
+            "partition_on_every_rank": (all(str(r["farm_partition"]).startswith("applied") for r in per_rank) if per_rank else None)}
+
+
 def plumbing(rank, world):
     """--plumbing: the N-rank rendezvous on the CPU over gloo (no GPU, no ocean)."""
     import torch
@@ -336,10 +356,14 @@ def plumbing(rank, world):
     dist.all_reduce(t)
     g = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(g, torch.tensor([float(rank)], dtype=torch.float64))
+    # the N > 1 line's per-rank reports through the same calls the timed run makes (made-up times: rank r computed 1 + r / 10 ms, gathered 0.9 ms)
+    box = [None] * world
+    dist.all_gather_object(box, rank_report(rank, 0, 1.0 + 0.1 * rank, 0.9, 1.2, 1.0, "applied: 32 of 256 compute units for the communication stream" if rank % 2 == 0 else "refused (32 asked): plumbing", None))
     dist.barrier()
     if rank == 0:
         print(json.dumps({"plumbing": "ok", "backend": "gloo", "world_size": dist.get_world_size(), "sum_of_ranks": float(t.item()),
-                          "ranks_seen": [int(v.item()) for v in g], "launcher": "bench.py" if os.environ.get("DATUM_BENCH_CHILD") else "external"}), flush=True)
+                          "ranks_seen": [int(v.item()) for v in g], "launcher": "bench.py" if os.environ.get("DATUM_BENCH_CHILD") else "external",
+                          "farm_diagnostics": farm_diagnostics(box, world, 50331648, 0.9, 1.0 + 0.1 * (world - 1), True, True)}), flush=True)
     dist.destroy_process_group()
     return 0
 
@@ -727,11 +751,7 @@ def main():
     # collective time, whether its CU partition was applied or refused (and why), its RCCL and the channel settings in its environment
     per_rank = None
     if multi:
-        mine = {"rank": rank, "device": local_rank, "compute_ms": compute_ms, "gather_ms": gather_ms, "wall_ms": elapsed * 1e3,
-                "without_gather_ms": plain_elapsed * 1e3,
-                "farm_partition": partition_state,
-                "rccl_version": (farm_info["rccl_version"] if native else None),
-                "rccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_")) and k not in ("NCCL_DEBUG_FILE",)}}
+        mine = rank_report(rank, local_rank, compute_ms, gather_ms, elapsed * 1e3, plain_elapsed * 1e3, partition_state, (farm_info["rccl_version"] if native else None))
         box = [None] * world
         dist.all_gather_object(box, mine)
         per_rank = box
@@ -857,13 +877,7 @@ def main():
             "gather_ms": gather_ms,
             # N > 1 only.  bus_GBps: what every rank RECEIVES in one all-gather, (world - 1) payloads, over the slowest rank's collective
             # time -- the figure DESIGN.md section 6's prediction assumes to be >= 270 GB/s; per_rank: each rank's own view
-            "farm_diagnostics": ({"per_rank": per_rank,
-                                  "gather_ms_max": gather_ms,
-                                  "bytes_received_per_rank": (world - 1) * pbytes if gathering else None,
-                                  "bus_GBps": ((world - 1) * pbytes / (gather_ms * 1e-3) / 1e9 if (gathering and gather_ms > 0 and world > 1) else None),
-                                  "gather_hidden_under_compute": (bool(gather_ms <= compute_ms) if (gathering and args.gather == "pipelined") else None),
-                                  "partition_on_every_rank": (all(str(r["farm_partition"]).startswith("applied") for r in per_rank) if per_rank else None)}
-                                 if multi else None),
+            "farm_diagnostics": (farm_diagnostics(per_rank, world, pbytes if gathering else 0, gather_ms, compute_ms, gathering, args.gather == "pipelined") if multi else None),
             "gen": gen,
             "reference_frame_n64": frame,
             "value_compute_only": grids / (compute_ms * 1e-3) if (compute_ms > 0 and args.gather != "serial") else None,

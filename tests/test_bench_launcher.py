@@ -28,6 +28,12 @@ def test_own_launcher_starts_n_ranks(world):
     j = json.loads(lines[0])
     assert j["plumbing"] == "ok" and j["world_size"] == world and j["launcher"] == "bench.py"
     assert j["ranks_seen"] == list(range(world)) and j["sum_of_ranks"] == world * (world - 1) / 2
+    # the N > 1 line's self-diagnosis (every rank's report gathered as objects, then summarised) through the calls the timed run makes
+    d = j["farm_diagnostics"]
+    assert [r["rank"] for r in d["per_rank"]] == list(range(world)) and all(isinstance(r["rccl_env"], dict) for r in d["per_rank"])
+    assert d["slowest_rank"] == world - 1 and d["compute_ms_spread"] == [1.0, pytest.approx(1.0 + 0.1 * (world - 1))]
+    assert d["bus_GBps"] == pytest.approx((world - 1) * 50331648 / 0.9e-3 / 1e9) and d["gather_hidden_under_compute"] is True
+    assert d["partition_on_every_rank"] is False and d["per_rank"][1]["farm_partition"].startswith("refused")
 
 
 def test_under_an_external_launcher():
