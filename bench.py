@@ -570,10 +570,25 @@ def main():
     # dispatch is not prepared under a sampled one's tail): at 20 steps every 2nd step sampled takes 6 % off the
     # throughput being measured, every 4th 3 %, every 8th 1.5 % (tools/stride_check.sh) -- about 5 samples of each kernel below
     # 64 steps (every 4th step at the driver's 20), every 8th step from 64 steps up (DATUM_BENCH_STRIDE overrides)
-    # -- and every 32nd step from 512 steps up (the default 2000 steps: 63 samples of each kernel, 0.4 % instead of 1.5 %)
-    stride = int(os.environ.get("DATUM_BENCH_STRIDE", "0")) or (32 if args.steps >= 512 else (8 if args.steps >= 64 else max(1, args.steps // 5)))
-    oc.profile_begin((args.steps + stride - 1) // stride, stride)
+    # -- and every 32nd step from 512 steps up (the default 2000 steps: 63 samples of each kernel, 0.4 % instead of 1.5 %).
+    # Round 6, measured at the driver's 20 steps (one box, --steps 20 --warmup 5): every step sampled 68.5 k grids/s, every 4th (five samples, the
+    # rule up to here) 76.3 k, every 10th (two) 78.9 k, one sample 80.0 k -- a sampled step costs the loop ~8 us, i.e. the roofline's own
+    # measurement took 4.6 % off the figure it rides on.  Below 64 steps the timed region therefore carries TWO samples of each kernel (a quarter
+    # and three quarters of the way through: the first step behind the barrier starts on an idle device and is not typical), and the same kernels
+    # are timed on EVERY step of a second, untimed pass right behind it (roofline.after_region), which says whether the two were representative.
+    stride = int(os.environ.get("DATUM_BENCH_STRIDE", "0")) or (32 if args.steps >= 512 else (8 if args.steps >= 64 else max(1, args.steps // 2)))
+    first_sample = args.steps // 4 if (args.steps < 64 and "DATUM_BENCH_STRIDE" not in os.environ) else 0
+    nsamples = (args.steps - first_sample + stride - 1) // stride
+    oc.profile_begin(nsamples, stride)             # (the events exist from here on; the sampling proper is switched on at step `first_sample`)
+    oc.profile_end()
     ev0, ev1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+    steps_done = [0]
+
+    def timed_step():
+        if steps_done[0] == first_sample:
+            oc.profile_begin(nsamples, stride)     # a host-side switch: no GPU work, and the host runs several steps ahead of the device
+        steps_done[0] += 1
+        step()
 
     # The timed region holds exactly --steps steps, one pack and one all-gather.  pipelined: the field as it stands when the
     # batch begins (the previous batch's result) is packed and its all-gather runs on the communication stream while this
@@ -587,7 +602,7 @@ def main():
     ev0.record(stream)
     if every > 0:
         for i in range(args.steps):
-            step()
+            timed_step()
             if (i + 1) % every == 0:
                 slot = gather()
                 gathers += 1
@@ -602,18 +617,18 @@ def main():
         # (tools/gather_overhead.sh, stand-in only: DATUM_STANDIN_CHUNKS slices of the transfer, one every steps / chunks steps)
         chunks = tg.standin_chunks if (tg is not None and getattr(tg, "standin_lib", None) is not None) else 1
         for i in range(args.steps):
-            step()
+            timed_step()
             if chunks > 1 and (i + 1) % max(1, args.steps // chunks) == 0:
                 tg.launch_more()
     elif gathering:
         for _ in range(args.steps):
-            step()
+            timed_step()
         slot = gather()
         gathers = 1
         await_gather(slot)
     else:
         for _ in range(args.steps):
-            step()
+            timed_step()
     ev1.record(stream)
     torch.cuda.synchronize(dev)      # both streams
     if multi:
@@ -622,6 +637,19 @@ def main():
     elapsed = time.perf_counter() - t0
 
     row_ms, col_ms, nprof = oc.profile_end()
+
+    # few samples inside the timed region (short runs): the same steps once more with every launch timed, outside the timed region
+    after_region = None
+    if nprof < 8 and not (multi and gathering):
+        na = min(args.steps, 40)
+        torch.cuda.synchronize(dev)
+        oc.profile_begin(na, 1)
+        for _ in range(na):
+            step()
+        torch.cuda.synchronize(dev)
+        arow, acol, an = oc.profile_end()
+        after_region = {"rowpass_ms": arow, "colpass_ms": acol, "steps_timed": an,
+                        "what": f"the two kernels on every one of {an} further steps right behind the timed region (dispatch events on every launch; not part of `value`)"}
 
     # SURVEY.md 8e asks for both figures: with the gather (the timed region above, `value`) and the tiles' throughput without it.
     # The same K steps once more, outside the timed region, no pack and no collective in flight; max over ranks like `value`.
@@ -870,6 +898,7 @@ def main():
                 "step_GBps": step_ach,
                 "step_frac": step_ach / HBM_PEAK_GBS,
                 "launches_timed": nprof,
+                "after_region": after_region,
                 "hbm_regime": regime,
             },
             "parity": committed_parity(N),

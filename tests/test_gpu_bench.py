@@ -91,3 +91,31 @@ def test_one_rank_group_with_the_native_gather():
     assert d["per_rank"][0]["rccl_version"] > 20000 and isinstance(d["per_rank"][0]["rccl_env"], dict)
     assert d["per_rank"][0]["farm_partition"].startswith("applied" if cus >= 64 else "off")
     assert d["partition_on_every_rank"] == (cus >= 64) and d["bus_GBps"] is None          # (one rank receives nothing)
+
+
+def test_the_drivers_command_line():
+    # `python3 bench.py --gpus 1 --steps 20 --warmup 5` (BENCH_r03 ... r05's cmd): one line, the contract's keys, and the roofline's measurement
+    # kept light inside the timed region -- two samples of each kernel there (a sampled step costs the loop ~8 us of its ~1000), every step of a
+    # second pass behind it (roofline.after_region) to say that the two were representative
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert (j["n_gpus"], j["steps"], j["warmup"], j["unit"], j["scaling"], j["vs_baseline"], j["dtype"]) == (1, 20, 5, "grids/s", "weak", None, "f32")
+    assert "BASELINE.json configs[2]" in j["config"]["workload"] and j["config"]["map_stores"].startswith("written through")
+    rf = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] <= 1
+    assert rf["launches_timed"] == 2 and rf["after_region"]["steps_timed"] == 20
+    for k in ("rowpass", "colpass"):
+        inside, after = rf[k]["ms"], rf["after_region"][k + "_ms"]
+        assert 0.7 < inside / after < 1.4, (k, inside, after)
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert j["parity"]["displacement_rmse"]["fused_vs_reduced_table_oracle"] < 1e-5
+    assert j["value"] * j["ms_per_step"] * 1e-3 == pytest.approx(4.0, rel=1e-6)      # grids per step over seconds per step
