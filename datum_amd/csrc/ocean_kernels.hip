@@ -1482,7 +1482,9 @@ namespace ocean
       float2 v = h0[i];
       float a = fmaxf(fabsf(v.x), fabsf(v.y));
 
-      m = (a == a) ? fmaxf(m, a) : __builtin_inff();     // a NaN must not hide
+      // a NaN must not hide -- and fmaxf drops one: each component is looked at by itself (round 6: a NaN in ONE component of a point went
+      // through the fp16 formats unnoticed until then, tests/test_gpu_parity.py::test_fp16_formats_refuse_an_h0_that_is_not_finite)
+      m = (v.x == v.x && v.y == v.y) ? fmaxf(m, a) : __builtin_inff();
     }
 
     for(int o = 32; o > 0; o >>= 1)

@@ -989,6 +989,46 @@ def test_gen_ragged_mesh(capi, oracle, torch):
     assert np.all(got[..., 11] == -1)
 
 
+@pytest.mark.parametrize("fmt", ["fp16", "fp16h0"])
+def test_fp16_formats_refuse_an_h0_that_is_not_finite(capi, oracle, fmt):
+    # the fp16 formats size their power-of-two scales from max |h0| (and FP16_H0 its half copy of h0): a NaN or an infinity in h0 (F7: the
+    # reference's own seeding produces NaNs at a rate of 4.5e-6 per point) has no scale -- datum_ocean_displace says so (EINVAL) instead of
+    # storing garbage halves, nothing is launched, and the handle works again once a finite state is uploaded; in fp32 the same h0 displaces
+    # (and poisons its own cascade only, as the reference would)
+    N = 256
+    p = oracle.EXAMPLE
+    good = make_state(oracle, N, 1000)
+    with capi.Ocean(N, 2) as oc:
+        oc.set_spectrum_format(fmt)
+        for c in range(2):
+            oc.set_cascade(c, p["wavescale"], p["choppiness"])
+            oc.upload_state(c, good)
+        oc.update(DT)
+        oc.displace()
+        before = oc.read_maps(1)
+        for poison in (np.nan, np.inf):
+            bad = good.copy()
+            bad[17, 33, 1] = poison
+            oc.upload_state(1, bad)
+            oc.update(DT)
+            with pytest.raises(capi.OceanError) as e:
+                oc.displace()
+            assert e.value.code == capi.EINVAL and "NaN or an infinity" in str(e.value)
+            assert np.array_equal(oc.read_maps(1), before)          # nothing was launched
+        oc.upload_state(1, good)
+        oc.update(DT)
+        oc.displace()
+        a, b = oc.read_maps(0), oc.read_maps(1)
+        assert np.isfinite(a).all() and np.isfinite(b).all() and float(np.abs(b[0][..., 2]).max()) > 0
+        oc.set_spectrum_format("fp32")
+        bad = good.copy()
+        bad[17, 33, 1] = np.nan
+        oc.upload_state(1, bad)
+        oc.update(DT)
+        oc.displace()
+        assert np.isfinite(oc.read_maps(0)).all() and not np.isfinite(oc.read_maps(1)).all()
+
+
 @pytest.mark.parametrize("N", [64, 1024])
 def test_flat_ocean(capi, N):
     # the empty input: h0 = 0 everywhere -> zero displacement, normals exactly along z up to the reciprocal square
@@ -997,7 +1037,7 @@ def test_flat_ocean(capi, N):
         for c in range(2):
             oc.set_cascade(c, 22.0 * (c + 1), 1.35)
             oc.upload_state(c, np.zeros((N, N, 2), np.float32))
-        for fp16 in (False, True):
+        for fp16 in (False, True, "fp16h0"):
             oc.set_spectrum_format(fp16)
             oc.update(DT)
             oc.displace()
