@@ -1387,13 +1387,15 @@ def test_native_farm_on_partitioned_compute_units(capi, oracle, torch):
 
 
 @pytest.mark.parametrize("N,C,fmt", [(512, 2, "fp32"), (1024, 4, "fp32"), (1024, 7, "fp32"), (1024, 4, "fp16h0"), (2048, 1, "fp32"), (4096, 1, "fp16")])
-def test_map_store_policies_do_not_change_the_result(capi, oracle, N, C, fmt):
+def test_map_store_policies_do_not_change_the_result(capi, oracle, torch, N, C, fmt):
     # datum_ocean_set_map_store_policy (ABI 8): the maps written through or streamed past the Infinity Cache -- the same bits either way;
     # AUTO = written through while the handle's working set fits the cache (300 MB) and no multi-rank farm exists; below 1024^2 there is
     # only the written-through form, at 4096^2 only the streamed one; a changed policy may change the cascade groups (refused while profiling)
     p = oracle.EXAMPLE
     states = [make_state(oracle, N, 1000 + c, oracle.CASCADE_WAVESCALES[c % 4]) for c in range(min(C, 2))]
     out = {}
+    hs = capi.OceanSet.from_buffer_copy(bytes(oracle.example_oceanset(N, swellphase=0.2)))
+    verts = torch.empty(96 * 64 * 12, dtype=torch.float32, device="cuda:0")
     with capi.Ocean(N, C) as oc:
         oc.set_spectrum_format(fmt)
         for c in range(C):
@@ -1412,7 +1414,11 @@ def test_map_store_policies_do_not_change_the_result(capi, oracle, N, C, fmt):
             for _ in range(2):
                 oc.update(DT)
                 oc.displace()
-            out[policy] = [oc.read_maps(c) for c in range(C)]
+            # ocean.gen right behind the column pass, from the maps as that policy left them in the caches / in memory
+            oc.gen(C - 1, hs, 96, 64, verts.data_ptr())
+            oc.sync()
+            torch.cuda.synchronize()
+            out[policy] = [oc.read_maps(c) for c in range(C)] + [verts.cpu().numpy().copy()]
         oc.profile_begin(1, 1)
         with pytest.raises(capi.OceanError) as e:
             oc.set_map_store_policy("auto")
@@ -1429,8 +1435,10 @@ def test_map_store_policies_do_not_change_the_result(capi, oracle, N, C, fmt):
         oc.farm_shutdown()
     for c in range(C):
         assert float(np.abs(out["auto"][c][0][..., 2]).max()) > 0
+    for c in range(C + 1):                                            # (the last entry: ocean.gen's vertices from the last cascade)
         assert np.array_equal(out["auto"][c], out["written through"][c]), c
         assert np.array_equal(out["auto"][c], out["streamed"][c]), c
+    assert np.isfinite(out["auto"][C]).all() and float(np.abs(out["auto"][C]).max()) > 0
 
 
 @pytest.mark.parametrize("N,C,half", [(256, 5, False), (1024, 12, False), (1024, 6, True), (2048, 3, False)])
