@@ -132,7 +132,8 @@ namespace
         CHECK(datum_ocean_farm_release(hip, previous, nullptr, 1));
         CHECK(datum_ocean_farm_wait(hip, previous, &ms));
 
-        printf("rank %d batch %d gather %.3f ms tiles", rank, batch - 1, ms);
+        // (what the rank RECEIVED over the collective's time: the bus bandwidth DESIGN.md section 7's prediction assumes to be >= 270 GB/s at 8 ranks)
+        printf("rank %d batch %d gather %.3f ms (%.0f GB/s received) tiles", rank, batch - 1, ms, ms > 0 ? (double)(world - 1) * bytes / (ms * 1e-3) / 1e9 : 0.0);
 
         for(int r = 0; r < world; ++r)
         {
