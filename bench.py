@@ -905,7 +905,7 @@ def main():
             "compute_ms": compute_ms,
             "gather_ms": gather_ms,
             # N > 1 only.  bus_GBps: what every rank RECEIVES in one all-gather, (world - 1) payloads, over the slowest rank's collective
-            # time -- the figure DESIGN.md section 6's prediction assumes to be >= 270 GB/s; per_rank: each rank's own view
+            # time -- the figure DESIGN.md section 7's prediction assumes to be >= 270 GB/s; per_rank: each rank's own view
             "farm_diagnostics": (farm_diagnostics(per_rank, world, pbytes if gathering else 0, gather_ms, compute_ms, gathering, args.gather == "pipelined") if multi else None),
             "gen": gen,
             "reference_frame_n64": frame,
